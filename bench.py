@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- cells/s of the Snapshot+Log chunk build (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one pass of the hot path (dcdf_encoder_run: the fused HIP encoder over every chunk of the batch,
+heuristic + DAC/bitmap packing + serialization into HBM) over one batch of synthetic chunks that is already
+resident in HBM.  Workload at N=1 = BASELINE configs[1]: 1024 independent [32,256,256] chunks (seed
+0xDCDF0002 + c).  With N ranks every rank owns its own 1024 chunks (independent units, no data-path
+collective; torch.distributed/RCCL is used only for the barrier and the max-over-ranks of the time).
+
+Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
+  roofline     : algorithmic bytes (input cells * sizeof + encoded bytes) / HIP-event time of the encode kernel
+  cpu_baseline : the CPU oracle (C++ restatement of the reference, 1 thread like the reference) on a bounded
+                 sample of the same chunks, timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunks", type=int, default=1024, help="chunks per GPU (configs[1]: 1024)")
+    ap.add_argument("--instants", type=int, default=32)
+    ap.add_argument("--side", type=int, default=256)
+    ap.add_argument("--dtype", choices=["i32", "i64"], default="i32")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="chunks timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--verify", type=int, default=4, help="chunks compared byte-for-byte with the oracle (untimed)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from dcdf_amd import _lib as L
+    from dcdf_amd.encoder import Encoder, synth_fill
+
+    name = L.lib().dcdf_device_name()
+    if not name:
+        raise RuntimeError("libdcdf_k2r.so sees no GPU; the MI355X path has no CPU fallback")
+
+    n, T, S = args.chunks, args.instants, args.side
+    tdt = torch.int32 if args.dtype == "i32" else torch.int64
+    code = L.DCDF_I32 if args.dtype == "i32" else L.DCDF_I64
+    esz = 4 if args.dtype == "i32" else 8
+    data = torch.empty((n, T, S, S), dtype=tdt, device="cuda")
+    base_seed = 0xDCDF0002 + rank * n
+    for c in range(n):
+        synth_fill(data[c].data_ptr(), code, base_seed + c, 0, T, 0, S, 0, S)
+    torch.cuda.synchronize()
+
+    descs = [(data[c].data_ptr(), code, (S * S, S, 1), (T, S, S)) for c in range(n)]
+    enc = Encoder(descs, k=2)
+    cells_per_step = n * T * S * S
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        enc.run()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kernel_ms.append(enc.run())  # launches on the session stream and waits for it
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    bad = sum(1 for i in range(n) if enc.result(i)[0] != 0)
+    out_bytes = enc.total_bytes()
+    snaps = sum(enc.result(i)[2] for i in range(n))
+
+    # ---- untimed parity spot check against the oracle (rank 0) -------------------------------------
+    verified = 0
+    cpu = None
+    if rank == 0:
+        import oracle_lib as O
+        for c in range(min(args.verify, n)):
+            host = data[c].cpu().numpy()
+            assert enc.fetch(c) == O.chunk_build(host), "chunk %d: encoded bytes differ from the oracle" % c
+            verified += 1
+        if world == 1 and args.cpu_sample > 0:
+            m = min(args.cpu_sample, n)
+            sample = data[:m].cpu().numpy()
+            sec, tb, _ = O.bench_build(sample)
+            cpu = {"value": m * T * S * S / sec, "unit": "cells/s", "cores": 1, "kind": "port",
+                   "sample": "first %d of the %d [%d,%d,%d] %s chunks (%.1f s); C++ restatement of the Rust "
+                             "reference, serial like superchunk.rs:166-188" % (m, n, T, S, S, args.dtype, sec)}
+
+    if rank == 0:
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = cells_per_step * esz + out_bytes  # every input cell read once, every output byte written once
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "raster cells/s encoded (Snapshot+Log build)",
+            "value": cells_per_step * world * args.steps / elapsed,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32" if args.dtype == "i32" else "int64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d independent [%d,%d,%d] %s chunks per GPU, seed 0xDCDF0002+c" %
+                                   (n, T, S, S, args.dtype),
+                       "chunks_per_gpu": n, "k": 2, "device": name.decode(), "failed_tiles": bad,
+                       "encoded_bytes_per_gpu": out_bytes, "snapshots": snaps, "bytes_verified_vs_oracle": verified},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k2r::k_encode<8,false,true>", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,417 @@
+// k2r_capi_encode.hip -- C ABI, encode side (include/dcdf_k2r.h).  Host code only.
+//
+// dcdf_encoder = a device-resident encode session: tile descriptors, per-tile output slots,
+// per-class work queues.  dcdf_chunk_build_batch = upload + session + fetch.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "k2r_launch.h"
+#include "k2r_runtime.h"
+
+using namespace k2r;
+
+namespace k2r {
+
+Runtime& Runtime::get() {
+    static Runtime rt;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return;
+        rt.device = dev;
+        rt.cus = p.multiProcessorCount;
+        rt.name = std::string(p.gcnArchName) + " " + p.name + ", " + std::to_string(p.multiProcessorCount) + " CUs";
+        rt.ok = true;
+    });
+    return rt;
+}
+
+static uint32_t sidelen_log2(uint32_t rows, uint32_t cols) {  // snapshot.rs:118-119 for k = 2
+    uint32_t m = std::max(rows, cols);
+    uint32_t lg = 0;
+    while ((1u << lg) < m) lg++;
+    return lg;
+}
+static size_t elem_size(int dtype) { return (dtype == DCDF_I32 || dtype == DCDF_F32) ? 4 : 8; }
+
+// Upper bound of one serialized instant (all values 4 bytes): used when the default slot overflows.
+static uint64_t worst_instant_bytes(uint32_t lg) {
+    const uint64_t maxv = ((1ull << (2 * (lg + 1))) - 1) / 3, maxt = ((1ull << (2 * lg)) - 1) / 3;
+    auto bm = [](uint64_t n) { return 8 + 4 * (n / 128) + 4 * ((n + 31) / 32); };
+    return 13 + 2 * bm(maxt) + (1 + 4 * (bm(maxv) + maxv)) + (1 + 4 * (bm(maxt) + maxt));
+}
+
+}  // namespace k2r
+
+struct dcdf_encoder {
+    std::vector<dcdf_tile_desc> desc;
+    std::vector<TileArgs> args;        // host mirror of the device array
+    std::vector<TileResult> results;   // host copy after run
+    std::vector<int32_t> pre_status;   // host-side validation result per tile
+    std::vector<EncClass> classes;
+    std::vector<std::vector<uint32_t>> class_tiles;
+    std::vector<uint64_t> slot_off, slot_cap;
+    DevBuf d_args, d_results, d_out, d_minmax, d_order, d_queue, d_lists;
+    std::vector<size_t> order_off;     // per class offset into d_order
+    std::vector<size_t> lists_off;     // per class offset (u64 words) into d_lists
+    std::vector<uint32_t> grid;
+    std::vector<std::unique_ptr<DevBuf>> retry_slots;  // bigger slots for tiles that overflowed
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t minmax_total = 0;
+    std::vector<uint64_t> minmax_off;
+    ~dcdf_encoder() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls) {
+    if (!t.base || t.instants == 0 || t.rows == 0 || t.cols == 0) return DCDF_ERR_BAD_ARG;
+    if (t.dtype != DCDF_I32 && t.dtype != DCDF_I64 && t.dtype != DCDF_F32 && t.dtype != DCDF_F64) return DCDF_ERR_BAD_ARG;
+    if ((t.dtype == DCDF_F32 || t.dtype == DCDF_F64) && t.fractional_bits > 62) return DCDF_ERR_BAD_ARG;
+    if (k != 2) return DCDF_ERR_UNSUPPORTED;
+    const uint32_t lg = sidelen_log2(t.rows, t.cols);
+    if (lg < 3 || lg > 8) return DCDF_ERR_UNSUPPORTED;  // fast path covers sidelen 8..256
+    const uint32_t S = 1u << lg;
+    cls->log2s = (int)lg;
+    cls->padded = t.rows != S || t.cols != S;
+    cls->vec = !cls->padded && t.dtype == DCDF_I32 && t.stride_c == 1 && (t.stride_r % 4) == 0 &&
+               (t.stride_t % 4) == 0 && ((uintptr_t)t.base % 16) == 0;
+    return DCDF_OK;
+}
+
+extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k, size_t out_cap_per_tile,
+                                   dcdf_encoder** enc_out) {
+    if (!tiles || !enc_out || n == 0 || n > 0x7fffffffu) return DCDF_ERR_BAD_ARG;
+    Runtime& rt = Runtime::get();
+    if (!rt.ok) return DCDF_ERR_NO_DEVICE;
+    std::unique_ptr<dcdf_encoder> e(new (std::nothrow) dcdf_encoder());
+    if (!e) return DCDF_ERR_NOMEM;
+    e->desc.assign(tiles, tiles + n);
+    e->args.resize(n);
+    e->results.resize(n);
+    e->pre_status.resize(n);
+    e->slot_off.resize(n);
+    e->slot_cap.resize(n);
+    e->minmax_off.resize(n);
+    uint64_t out_total = 0, mm_total = 0;
+    for (size_t i = 0; i < n; i++) {
+        const dcdf_tile_desc& t = tiles[i];
+        EncClass cls{};
+        const int st = validate_tile(t, k, &cls);
+        e->pre_status[i] = st;
+        e->results[i] = TileResult{};
+        if (st != DCDF_OK) continue;
+        size_t ci = 0;
+        for (; ci < e->classes.size(); ci++)
+            if (e->classes[ci] == cls) break;
+        if (ci == e->classes.size()) {
+            e->classes.push_back(cls);
+            e->class_tiles.emplace_back();
+        }
+        e->class_tiles[ci].push_back((uint32_t)i);
+        uint64_t cap = out_cap_per_tile ? out_cap_per_tile : (uint64_t)t.instants * t.rows * t.cols * 4 + 4096;
+        cap = (cap + 255) & ~255ull;
+        e->slot_off[i] = out_total;
+        e->slot_cap[i] = cap;
+        out_total += cap;
+        e->minmax_off[i] = mm_total;
+        mm_total += 2ull * t.instants;
+    }
+    e->minmax_total = mm_total;
+    K2R_HIP(hipStreamCreate(&e->stream));
+    K2R_HIP(hipEventCreate(&e->ev0));
+    K2R_HIP(hipEventCreate(&e->ev1));
+    K2R_HIP(e->d_out.alloc(out_total));
+    K2R_HIP(e->d_minmax.alloc(mm_total * 8));
+    K2R_HIP(e->d_args.alloc(n * sizeof(TileArgs)));
+    K2R_HIP(e->d_results.alloc(n * sizeof(TileResult)));
+    for (size_t i = 0; i < n; i++) {
+        const dcdf_tile_desc& t = tiles[i];
+        TileArgs a{};
+        a.base = t.base;
+        a.st = t.stride_t; a.sr = t.stride_r; a.sc = t.stride_c;
+        a.instants = t.instants; a.rows = t.rows; a.cols = t.cols;
+        a.dtype = t.dtype;
+        a.fbits = (t.dtype == DCDF_F32 || t.dtype == DCDF_F64) ? t.fractional_bits : 0;  // mmbuffer.rs:397-403
+        a.round = t.round;
+        a.out = e->d_out.as<uint8_t>() + e->slot_off[i];
+        a.out_cap = e->slot_cap[i];
+        a.minmax = e->d_minmax.as<int64_t>() + e->minmax_off[i];
+        e->args[i] = a;
+    }
+    // per-class launch geometry
+    size_t order_total = 0, lists_total = 0;
+    for (size_t ci = 0; ci < e->classes.size(); ci++) {
+        const EncClass& c = e->classes[ci];
+        const uint32_t nt = (uint32_t)e->class_tiles[ci].size();
+        const int per_cu = encode_blocks_per_cu(c);
+        uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)rt.cus * (uint64_t)per_cu);
+        e->grid.push_back(std::max(1u, g));
+        e->order_off.push_back(order_total);
+        order_total += nt;
+        e->lists_off.push_back(lists_total);
+        lists_total += (size_t)e->grid.back() * encode_list_words(c);
+    }
+    K2R_HIP(e->d_order.alloc(std::max<size_t>(order_total, 1) * 4));
+    K2R_HIP(e->d_queue.alloc(std::max<size_t>(e->classes.size(), 1) * 4));
+    K2R_HIP(e->d_lists.alloc(std::max<size_t>(lists_total, 1) * 8));
+    for (size_t ci = 0; ci < e->classes.size(); ci++) {
+        // longest chunks first: the tail of the work queue is then made of the short ones
+        auto& v = e->class_tiles[ci];
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return tiles[a].instants > tiles[b].instants; });
+        K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    }
+    K2R_HIP(hipMemcpy(e->d_args.p, e->args.data(), n * sizeof(TileArgs), hipMemcpyHostToDevice));
+    *enc_out = e.release();
+    return DCDF_OK;
+}
+
+static int run_classes(dcdf_encoder* e, const std::vector<std::vector<uint32_t>>* subset, float* kernel_ms) {
+    // subset == nullptr: all tiles of every class (order already on the device)
+    K2R_HIP(hipMemsetAsync(e->d_queue.p, 0, e->d_queue.bytes, e->stream));
+    K2R_HIP(hipEventRecord(e->ev0, e->stream));
+    for (size_t ci = 0; ci < e->classes.size(); ci++) {
+        uint32_t nt = (uint32_t)e->class_tiles[ci].size();
+        if (subset) {
+            nt = (uint32_t)(*subset)[ci].size();
+            if (nt == 0) continue;
+            K2R_HIP(hipMemcpyAsync(e->d_order.as<uint32_t>() + e->order_off[ci], (*subset)[ci].data(), nt * 4ull,
+                                   hipMemcpyHostToDevice, e->stream));
+        }
+        EncodeLaunch L{};
+        L.tiles = e->d_args.as<TileArgs>();
+        L.results = e->d_results.as<TileResult>();
+        L.order = e->d_order.as<uint32_t>() + e->order_off[ci];
+        L.n = nt;
+        L.queue = e->d_queue.as<uint32_t>() + ci;
+        L.lists = e->d_lists.as<uint64_t>() + e->lists_off[ci];
+        L.grid = std::min(e->grid[ci], std::max(1u, nt));
+        K2R_HIP(launch_encode(e->classes[ci], L, e->stream));
+    }
+    K2R_HIP(hipEventRecord(e->ev1, e->stream));
+    K2R_HIP(hipStreamSynchronize(e->stream));
+    if (kernel_ms) K2R_HIP(hipEventElapsedTime(kernel_ms, e->ev0, e->ev1));
+    return DCDF_OK;
+}
+
+extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
+    if (!e) return DCDF_ERR_BAD_ARG;
+    const size_t n = e->desc.size();
+    int rc = run_classes(e, nullptr, kernel_ms);
+    if (rc != DCDF_OK) return rc;
+    K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
+    // Tiles whose slot was too small: re-encode them alone into worst-case slots (rare; not timed).
+    std::vector<std::vector<uint32_t>> again(e->classes.size());
+    bool any = false;
+    for (size_t ci = 0; ci < e->classes.size(); ci++)
+        for (uint32_t ti : e->class_tiles[ci])
+            if (e->results[ti].status == ST_OUT_CAPACITY) {
+                const dcdf_tile_desc& t = e->desc[ti];
+                const uint64_t cap = 6 + (uint64_t)t.instants * (1 + worst_instant_bytes((uint32_t)e->classes[ci].log2s));
+                std::unique_ptr<DevBuf> b(new DevBuf());
+                K2R_HIP(b->alloc(cap));
+                e->args[ti].out = b->as<uint8_t>();
+                e->args[ti].out_cap = cap;
+                e->retry_slots.push_back(std::move(b));
+                K2R_HIP(hipMemcpy(e->d_args.as<TileArgs>() + ti, &e->args[ti], sizeof(TileArgs), hipMemcpyHostToDevice));
+                again[ci].push_back(ti);
+                any = true;
+            }
+    if (any) {
+        rc = run_classes(e, &again, nullptr);
+        if (rc != DCDF_OK) return rc;
+        K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
+        // restore the full order lists for a later run()
+        for (size_t ci = 0; ci < e->classes.size(); ci++)
+            K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], e->class_tiles[ci].data(),
+                              e->class_tiles[ci].size() * 4, hipMemcpyHostToDevice));
+    }
+    return DCDF_OK;
+}
+
+extern "C" int dcdf_encoder_result(dcdf_encoder* e, size_t i, int32_t* status, uint64_t* len, uint32_t* snapshots,
+                                   uint32_t* logs, const uint8_t** device_bytes) {
+    if (!e || i >= e->desc.size()) return DCDF_ERR_BAD_ARG;
+    const bool pre_ok = e->pre_status[i] == DCDF_OK;
+    const TileResult& r = e->results[i];
+    const int st = pre_ok ? map_status(r.status) : e->pre_status[i];
+    if (status) *status = st;
+    if (len) *len = st == DCDF_OK ? r.len : 0;
+    if (snapshots) *snapshots = st == DCDF_OK ? r.snapshots : 0;
+    if (logs) *logs = st == DCDF_OK ? r.logs : 0;
+    if (device_bytes) *device_bytes = st == DCDF_OK ? e->args[i].out : nullptr;
+    return DCDF_OK;
+}
+
+extern "C" int dcdf_encoder_fetch(dcdf_encoder* e, size_t i, uint8_t* dst, size_t cap) {
+    if (!e || i >= e->desc.size() || !dst) return DCDF_ERR_BAD_ARG;
+    if (e->pre_status[i] != DCDF_OK) return e->pre_status[i];
+    const TileResult& r = e->results[i];
+    if (r.status != ST_OK) return map_status(r.status);
+    if (cap < r.len) return DCDF_ERR_CAPACITY;
+    K2R_HIP(hipMemcpy(dst, e->args[i].out, r.len, hipMemcpyDeviceToHost));
+    return DCDF_OK;
+}
+
+extern "C" uint64_t dcdf_encoder_total_bytes(dcdf_encoder* e) {
+    uint64_t s = 0;
+    if (!e) return 0;
+    for (size_t i = 0; i < e->desc.size(); i++)
+        if (e->pre_status[i] == DCDF_OK && e->results[i].status == ST_OK) s += e->results[i].len;
+    return s;
+}
+
+extern "C" void dcdf_encoder_destroy(dcdf_encoder* e) { delete e; }
+
+// ---- host-buffer convenience: Chunk::build for a batch ------------------------------------------------
+extern "C" void dcdf_free_encoded(dcdf_encoded* out, size_t n) {
+    if (!out) return;
+    for (size_t i = 0; i < n; i++) {
+        std::free(out[i].bytes);
+        std::free(out[i].minmax);
+    }
+    std::free(out);
+}
+
+static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dcdf_encoded* out) {
+    // tiles[0..n) fit the staging budget; host tiles are packed contiguously and uploaded
+    std::vector<dcdf_tile_desc> dev(tiles, tiles + n);
+    DevBuf stage;
+    if (mem == DCDF_MEM_HOST) {
+        uint64_t total = 0;
+        std::vector<uint64_t> off(n);
+        for (size_t i = 0; i < n; i++) {
+            off[i] = total;
+            const dcdf_tile_desc& t = tiles[i];
+            if (!t.base || t.instants == 0 || t.rows == 0 || t.cols == 0) continue;
+            total += ((uint64_t)t.instants * t.rows * t.cols * elem_size(t.dtype) + 255) & ~255ull;
+        }
+        K2R_HIP(stage.alloc(total));
+        std::vector<uint8_t> pack;
+        for (size_t i = 0; i < n; i++) {
+            const dcdf_tile_desc& t = tiles[i];
+            if (!t.base || t.instants == 0 || t.rows == 0 || t.cols == 0) continue;
+            if (t.dtype != DCDF_I32 && t.dtype != DCDF_I64 && t.dtype != DCDF_F32 && t.dtype != DCDF_F64) continue;
+            const size_t es = elem_size(t.dtype);
+            const uint64_t bytes = (uint64_t)t.instants * t.rows * t.cols * es;
+            const uint8_t* src = (const uint8_t*)t.base;
+            const bool contiguous = t.stride_c == 1 && t.stride_r == (int64_t)t.cols &&
+                                    t.stride_t == (int64_t)t.rows * t.cols;
+            if (!contiguous) {  // gather the strided view (mmbuffer.rs:517-522 tile slices)
+                pack.resize(bytes);
+                uint8_t* d = pack.data();
+                for (uint32_t a = 0; a < t.instants; a++)
+                    for (uint32_t r = 0; r < t.rows; r++) {
+                        const uint8_t* row = src + ((int64_t)a * t.stride_t + (int64_t)r * t.stride_r) * (int64_t)es;
+                        if (t.stride_c == 1) {
+                            std::memcpy(d, row, (size_t)t.cols * es);
+                            d += (size_t)t.cols * es;
+                        } else {
+                            for (uint32_t c = 0; c < t.cols; c++, d += es)
+                                std::memcpy(d, row + (int64_t)c * t.stride_c * (int64_t)es, es);
+                        }
+                    }
+                src = pack.data();
+            }
+            K2R_HIP(hipMemcpy(stage.as<uint8_t>() + off[i], src, bytes, hipMemcpyHostToDevice));
+            dev[i].base = stage.as<uint8_t>() + off[i];
+            dev[i].stride_c = 1;
+            dev[i].stride_r = t.cols;
+            dev[i].stride_t = (int64_t)t.rows * t.cols;
+        }
+    }
+    dcdf_encoder* e = nullptr;
+    int rc = dcdf_encoder_create(dev.data(), n, k, 0, &e);
+    if (rc != DCDF_OK) return rc;
+    std::unique_ptr<dcdf_encoder> guard(e);
+    rc = dcdf_encoder_run(e, nullptr);
+    if (rc != DCDF_OK) return rc;
+    std::vector<int64_t> mm(e->minmax_total);
+    if (e->minmax_total) K2R_HIP(hipMemcpy(mm.data(), e->d_minmax.p, e->minmax_total * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        int32_t st;
+        uint64_t len;
+        uint32_t ns, nl;
+        dcdf_encoder_result(e, i, &st, &len, &ns, &nl, nullptr);
+        out[i].status = st;
+        out[i].len = 0;
+        out[i].bytes = nullptr;
+        out[i].minmax = nullptr;
+        out[i].snapshots = ns;
+        out[i].logs = nl;
+        if (st != DCDF_OK) continue;
+        out[i].bytes = (uint8_t*)std::malloc(len ? len : 1);
+        out[i].minmax = (int64_t*)std::malloc(16ull * tiles[i].instants);
+        if (!out[i].bytes || !out[i].minmax) return DCDF_ERR_NOMEM;
+        rc = dcdf_encoder_fetch(e, i, out[i].bytes, len);
+        if (rc != DCDF_OK) return rc;
+        out[i].len = len;
+        std::memcpy(out[i].minmax, mm.data() + e->minmax_off[i], 16ull * tiles[i].instants);
+    }
+    return DCDF_OK;
+}
+
+extern "C" int dcdf_chunk_build_batch(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dcdf_encoded** out) {
+    if (!tiles || !out || n == 0 || (mem != DCDF_MEM_HOST && mem != DCDF_MEM_DEVICE)) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    dcdf_encoded* res = (dcdf_encoded*)std::calloc(n, sizeof(dcdf_encoded));
+    if (!res) return DCDF_ERR_NOMEM;
+    const uint64_t budget = 4ull << 30;  // raw bytes staged per group
+    size_t i = 0;
+    while (i < n) {
+        uint64_t acc = 0;
+        size_t j = i;
+        while (j < n) {
+            const uint64_t b = (uint64_t)tiles[j].instants * tiles[j].rows * tiles[j].cols * elem_size(tiles[j].dtype);
+            if (j > i && acc + b > budget) break;
+            acc += b;
+            j++;
+        }
+        const int rc = build_group(tiles + i, j - i, k, mem, res + i);
+        if (rc != DCDF_OK) {
+            dcdf_free_encoded(res, n);
+            return rc;
+        }
+        i = j;
+    }
+    *out = res;
+    return DCDF_OK;
+}
+
+extern "C" int dcdf_chunk_build(const dcdf_tile_desc* tile, int k, int mem, dcdf_encoded** out) {
+    return dcdf_chunk_build_batch(tile, 1, k, mem, out);
+}
+
+extern "C" const char* dcdf_strerror(int code) {
+    switch (code) {
+        case DCDF_OK: return "ok";
+        case DCDF_ERR_BAD_ARG: return "bad argument";
+        case DCDF_ERR_NONFINITE: return "cannot convert a non-finite float to fixed point (fixed.rs:39-41)";
+        case DCDF_ERR_PRECISION: return "fixed-point conversion loses precision and round is false (fixed.rs:47-59)";
+        case DCDF_ERR_OVERFLOW: return "fixed-point value overflows i64 (fixed.rs:65-70)";
+        case DCDF_ERR_BOUNDS: return "query out of bounds";
+        case DCDF_ERR_TOO_MANY_LOGS: return "too many logs in one block (block.rs:27-32)";
+        case DCDF_ERR_FORMAT: return "malformed encoded chunk";
+        case DCDF_ERR_UNSUPPORTED: return "unsupported by the MI355X fast path (k != 2, sidelen outside 8..256, or |value| >= 2^30)";
+        case DCDF_ERR_NO_DEVICE: return "no usable gfx950 device / HIP failure";
+        case DCDF_ERR_NOMEM: return "out of memory";
+        case DCDF_ERR_CAPACITY: return "result buffer too small";
+    }
+    return "unknown error";
+}
+extern "C" const char* dcdf_device_name(void) {
+    Runtime& rt = Runtime::get();
+    return rt.ok ? rt.name.c_str() : nullptr;
+}
+extern "C" int dcdf_abi_version(void) { return 1; }

@@ -1,0 +1,97 @@
+// k2r_common.h -- shared definitions for the MI355X K^2-raster engine.
+//
+// The kernel bodies in k2r_encode.h / k2r_decode.h are written against a tiny
+// "execution context" (k2r_exec.h).  The shipped library instantiates them
+// with the gfx950 context only (HIP kernels in k2r_kernels.hip).  The very same
+// source is also compiled by g++ with a sequential context in tests/sim/ so the
+// kernel logic can be checked (ASan/UBSan) on a machine without a GPU before it
+// ever touches the card.  That simulator is test infrastructure: it is not part
+// of libdcdf_k2r.so and nothing in the product path can reach it.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define K2R_HD __host__ __device__ __forceinline__
+#define K2R_D __device__ __forceinline__
+#else
+#define K2R_HD inline __attribute__((always_inline))
+#define K2R_D inline __attribute__((always_inline))
+#endif
+
+namespace k2r {
+
+// status codes stored per tile (mirror include/dcdf_k2r.h)
+enum : int32_t {
+    ST_OK = 0,
+    ST_BAD_ARG = -1,
+    ST_NONFINITE = -2,
+    ST_PRECISION = -3,
+    ST_OVERFLOW = -4,
+    ST_UNSUPPORTED = -8,
+    ST_OUT_CAPACITY = -100,  // internal: output slot too small, host retries with a bigger slot
+};
+
+enum : int32_t { ENC_I32 = 4, ENC_I64 = 8, ENC_F32 = 32, ENC_F64 = 64 };
+
+// Fast path value-range contract: every stored value v of the tile satisfies |v| < 2^30, so all
+// node differences are exact in int32 and every zig-zag code fits 4 bytes.
+constexpr int32_t VALUE_LIMIT = 1 << 30;
+
+struct TileArgs {  // one Chunk::build input (device-visible copy of dcdf_tile_desc + output slot)
+    const void* base;
+    int64_t st, sr, sc;  // strides in elements
+    uint32_t instants, rows, cols;
+    int32_t dtype;
+    uint32_t fbits;
+    uint32_t round;
+    uint8_t* out;      // output slot
+    uint64_t out_cap;  // bytes
+    int64_t* minmax;   // [instants][2] or null
+};
+
+struct TileResult {
+    int32_t status;
+    uint32_t snapshots;
+    uint32_t logs;
+    uint32_t _pad;
+    uint64_t len;
+};
+
+K2R_HD uint32_t popc32(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+K2R_HD uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+
+// zig-zag of a 32-bit difference (dac.rs:134-137 restricted to |n| < 2^31)
+K2R_HD uint32_t zz32(int32_t n) { return ((uint32_t)n << 1) ^ (uint32_t)(n >> 31); }
+
+// bitmap.rs:169-171
+K2R_HD uint32_t bitmap_size(uint32_t nbits) { return 8u + 4u * (nbits / 128u) + 4u * ((nbits + 31u) / 32u); }
+
+// compact the even bits of x (bit0,2,4,..) into the low half
+K2R_HD uint32_t compact_even(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+// Morton index (row bit above col bit at every level; snapshot.rs:468-474 child order i*k+j)
+K2R_HD void morton_decode(uint32_t m, uint32_t& row, uint32_t& col) {
+    col = compact_even(m);
+    row = compact_even(m >> 1);
+}
+
+// big-endian u32 store at an arbitrary byte address (extio.rs:228-233)
+K2R_HD void store_be32(uint8_t* p, uint32_t w) {
+    p[0] = (uint8_t)(w >> 24);
+    p[1] = (uint8_t)(w >> 16);
+    p[2] = (uint8_t)(w >> 8);
+    p[3] = (uint8_t)w;
+}
+K2R_HD uint32_t load_be32(const uint8_t* p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+}  // namespace k2r

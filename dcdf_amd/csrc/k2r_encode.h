@@ -1,0 +1,990 @@
+// k2r_encode.h -- fused Heuristic K^2-Raster chunk encoder (k = 2, sidelen 8..256).
+//
+// Replaces, for one tile, the whole of `Chunk::build` + `Chunk::write_to`
+// (reference chunk.rs:42-96,235-243; snapshot.rs:108-156; log.rs:112-165; dac.rs:96-132;
+// bitmap.rs:44-112) with a data-parallel formulation.  One workgroup marches over the
+// instants of one chunk (the heuristic is sequential, chunk.rs:55-74); inside an instant
+// everything is parallel over the tile.
+//
+// Parallel formulation (not how the reference does it; results are bit-identical):
+//  * thread `tid` owns the 8x8 cell block whose Morton index is `tid` (row bit above col
+//    bit == the reference's child order i*k+j, snapshot.rs:468-474).  Its 64 cells live in
+//    registers in Morton order, so heights 0..3 of the quadtree are thread-local and level
+//    order == (tid, local Morton) order at every level.
+//  * heights 4..H live in LDS ("top" arrays), built bottom-up with H-3 barriers.
+//  * "internal" is a LOCAL predicate.  Snapshot: P(n) = min(n) != max(n) (snapshot.rs:133).
+//    Log: P(n) = min_t != max_t and not equal(n) (log.rs:137-152).  Both are monotone
+//    (P(child) => P(parent)), so a node is visited iff P(parent) and is internal iff P(n):
+//    no top-down pass is needed.
+//  * stream positions come from ONE workgroup exclusive scan of per-thread internal counts
+//    per height: first child of internal node #r at height h+1 sits at
+//    offV[h] + 4*r (cf. the decoder's 1 + rank(T, i)*k^2, snapshot.rs:177).
+//  * sizes are functions of counts only, so both candidates (Snapshot
+//    and Log, chunk.rs:57-60) are only COUNTED; the winner of chunk.rs:62 alone is emitted.
+//  * DAC planes >= 1 are rare: values needing more than one byte are appended to a per-
+//    workgroup overflow list and placed by rank over the previous plane's continuation
+//    bitmap (exactly the decoder's hop, dac.rs:83-90).
+//
+// Value-range contract of this fast path: |stored value| < 2^30 (int32 arithmetic is then
+// exact and every zig-zag code fits 4 bytes).  Tiles outside it report ST_UNSUPPORTED.
+#pragma once
+#include "k2r_exec.h"
+
+namespace k2r {
+
+template <int LOG2S>
+struct EncCfg {
+    static_assert(LOG2S >= 3 && LOG2S <= 8, "fast path covers sidelen 8..256");
+    static constexpr int H = LOG2S;  // tree height; cells are height 0
+    static constexpr int S = 1 << LOG2S;
+    static constexpr int NT = 1 << (2 * (LOG2S - 3));
+    static constexpr int NW = NT < 64 ? 1 : NT / 64;
+    static constexpr int NTOP = ((1 << (2 * (H - 2))) - 1) / 3;  // nodes at heights 3..H
+    static constexpr int MAXV = ((1 << (2 * (H + 1))) - 1) / 3;  // all nodes        (|Lmax|)
+    static constexpr int MAXT = ((1 << (2 * H)) - 1) / 3;        // nodes w/ children (|T|, max |Lmin|)
+    static constexpr int WV = (MAXV + 31) / 32;
+    static constexpr int WT = (MAXT + 31) / 32;
+    // offset of height h (3..H) inside the top arrays; height 3 first
+    static constexpr int top_off(int h) { return ((1 << (2 * (H - 2))) - (1 << (2 * (H - h + 1)))) / 3; }
+};
+
+template <class C>
+struct EncShared {
+    int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
+    uint32_t eq[C::NTOP];
+    uint32_t bmT[C::WT + 1], bmE[C::WT + 1];
+    uint32_t bmV[2][C::WV + 1];
+    uint32_t bmM[2][C::WT + 1];
+    uint32_t prefV[C::WV + 2], prefM[C::WT + 2];
+    uint64_t wsum[C::NW][MAX_SCAN_FIELDS];
+    uint64_t tot[MAX_SCAN_FIELDS];
+    uint32_t nlistV, nlistM;
+    int32_t err;
+    uint32_t work;
+};
+
+struct EncRegs {
+    int32_t t[64];  // the current instant's cells of this thread's 8x8 block, Morton order
+    uint64_t sc[MAX_SCAN_FIELDS];
+    uint64_t pf_lo, pf_top;  // saved exclusive prefixes of the chosen candidate
+};
+
+// ---- packed scan fields ------------------------------------------------------------------
+// lo : I1 @0 (16b) | I2 @16 (14b) | I3 @30 (12b)        internal counts at heights 1..3
+// top: I4 @0 (10b) | I5 @10 (8b) | I6 @18 (6b) | I7 @24 (4b) | I8 @28 (2b)
+// mx : c1 @0 | c2 @18 | c3 @36   (# Lmax values needing > 1, > 2, > 3 bytes)
+// mn : c1 @0 | c2 @16 | c3 @32   (# Lmin values ...)
+K2R_HD uint32_t unpackI(int h, uint64_t lo, uint64_t top) {
+    switch (h) {
+        case 1: return (uint32_t)(lo & 0xffffu);
+        case 2: return (uint32_t)((lo >> 16) & 0x3fffu);
+        case 3: return (uint32_t)((lo >> 30) & 0xfffu);
+        case 4: return (uint32_t)(top & 0x3ffu);
+        case 5: return (uint32_t)((top >> 10) & 0xffu);
+        case 6: return (uint32_t)((top >> 18) & 0x3fu);
+        case 7: return (uint32_t)((top >> 24) & 0xfu);
+        case 8: return (uint32_t)((top >> 28) & 0x3u);
+    }
+    return 0;
+}
+K2R_HD uint64_t packTop(int h) {  // contribution of one internal node at height h (4..8)
+    switch (h) {
+        case 4: return 1ull;
+        case 5: return 1ull << 10;
+        case 6: return 1ull << 18;
+        case 7: return 1ull << 24;
+        case 8: return 1ull << 28;
+    }
+    return 0;
+}
+
+struct Cls {  // counts of values needing > 1, > 2, > 3 bytes
+    uint32_t c1 = 0, c2 = 0, c3 = 0;
+    K2R_HD void add(uint32_t zz, bool on) {
+        c1 += (on && zz > 0xffu) ? 1u : 0u;
+        c2 += (on && zz > 0xffffu) ? 1u : 0u;
+        c3 += (on && zz > 0xffffffu) ? 1u : 0u;
+    }
+    K2R_HD void add(const Cls& o, bool on) {
+        c1 += on ? o.c1 : 0u;
+        c2 += on ? o.c2 : 0u;
+        c3 += on ? o.c3 : 0u;
+    }
+    K2R_HD uint64_t pack18() const { return (uint64_t)c1 | ((uint64_t)c2 << 18) | ((uint64_t)c3 << 36); }
+    K2R_HD uint64_t pack16() const { return (uint64_t)c1 | ((uint64_t)c2 << 16) | ((uint64_t)c3 << 32); }
+};
+
+// ---- geometry helpers ---------------------------------------------------------------------
+// cell (dr,dc) of an 8x8 block -> Morton register index
+constexpr int cell_m(int dr, int dc) {
+    return 16 * ((((dr >> 2) & 1) << 1) | ((dc >> 2) & 1)) + 4 * ((((dr >> 1) & 1) << 1) | ((dc >> 1) & 1)) +
+           (((dr & 1) << 1) | (dc & 1));
+}
+// Morton index m (0..63) -> (dr,dc)
+constexpr int m_dr(int m) { return (((m >> 5) & 1) << 2) | (((m >> 3) & 1) << 1) | ((m >> 1) & 1); }
+constexpr int m_dc(int m) { return (((m >> 4) & 1) << 2) | (((m >> 2) & 1) << 1) | (m & 1); }
+
+K2R_HD int32_t min4(int32_t a, int32_t b, int32_t c, int32_t d) {
+    int32_t x = a < b ? a : b, y = c < d ? c : d;
+    return x < y ? x : y;
+}
+K2R_HD int32_t max4(int32_t a, int32_t b, int32_t c, int32_t d) {
+    int32_t x = a > b ? a : b, y = c > d ? c : d;
+    return x > y ? x : y;
+}
+
+// in-kernel marker for "value outside the fast path's range"; ranks below every conversion error in the
+// workgroup-wide lds_min so that a genuine reference panic (fixed.rs:39-70) is what gets reported
+constexpr int32_t ERR_RANGE = -1;
+
+// ---- fixed point (fixed.rs:31-71), arithmetic in the input float type ------------------------
+template <class F>
+K2R_HD int64_t to_fixed_dev(F n, uint32_t bits, bool round, int32_t& err) {
+    if (n != n) return 0;
+    if (!(n - n == (F)0)) {  // +-inf
+        err = ST_NONFINITE;
+        return 0;
+    }
+    F shifted = n * (F)((int64_t)1 << bits);
+    const F tr = (F)__builtin_trunc((double)shifted);  // exact for float and double
+    const F fr = shifted - tr;
+    if (fr > (F)0) {
+        if (round) {
+            // round half away from zero; shifted > 0 here because fract() > 0 only for positives
+            F fl = tr;
+            shifted = (shifted - fl >= (F)0.5) ? fl + (F)1 : fl;
+        } else {
+            if (err == 0) err = ST_PRECISION;
+            return 0;
+        }
+    }
+    shifted = shifted * (F)2;
+    if (!(shifted >= (F)-9223372036854775808.0 && shifted < (F)9223372036854775808.0)) {
+        if (err == 0) err = ST_OVERFLOW;
+        return 0;
+    }
+    return (int64_t)shifted + 1;
+}
+
+// one cell -> stored int64 (MMBuffer3::get, mmbuffer.rs:301-308,565-571,627-633)
+K2R_HD int64_t load_stored(const TileArgs& ta, int64_t off, int32_t& err) {
+    switch (ta.dtype) {
+        case ENC_I32: return (int64_t)((const int32_t*)ta.base)[off];
+        case ENC_I64: return ((const int64_t*)ta.base)[off];
+        case ENC_F32: return to_fixed_dev<float>(((const float*)ta.base)[off], ta.fbits, ta.round != 0, err);
+        default: return to_fixed_dev<double>(((const double*)ta.base)[off], ta.fbits, ta.round != 0, err);
+    }
+}
+K2R_HD int32_t narrow(int64_t v, int32_t& err) {
+    if (v < -(int64_t)VALUE_LIMIT || v >= (int64_t)VALUE_LIMIT) {
+        if (err == 0) err = ERR_RANGE;
+        return 0;
+    }
+    return (int32_t)v;
+}
+
+// Loads the thread's 8x8 block of one instant (clamp-to-edge outside the tile when PADDED: a clamped
+// cell copies a valid cell of every partially valid ancestor, so min/max over all 64 registers equals
+// min/max over the valid cells; all-invalid nodes are recognised from geometry instead).
+template <bool PADDED, bool VEC>
+K2R_HD void load_block(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t c0, int32_t (&dst)[64], int32_t& err) {
+    if (VEC) {  // int32, unit column stride, 16-byte aligned rows, no padding
+        const int32_t* p = (const int32_t*)ta.base + (int64_t)inst * ta.st + (int64_t)r0 * ta.sr + c0;
+        uint32_t bad = 0;
+#pragma unroll
+        for (int dr = 0; dr < 8; dr++) {
+            const int32_t* q = p + (int64_t)dr * ta.sr;
+            int32_t v[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int4 a = *(const int4*)q;
+            const int4 b = *(const int4*)(q + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#else
+            for (int i = 0; i < 8; i++) v[i] = q[i];
+#endif
+#pragma unroll
+            for (int dc = 0; dc < 8; dc++) {
+                dst[cell_m(dr, dc)] = v[dc];
+                bad |= ((uint32_t)v[dc] + (uint32_t)VALUE_LIMIT) >> 31;
+            }
+        }
+        if (bad && err == 0) err = ERR_RANGE;
+    } else {
+#pragma unroll
+        for (int m = 0; m < 64; m++) {
+            uint32_t r = r0 + m_dr(m), c = c0 + m_dc(m);
+            if (PADDED) {
+                r = r < ta.rows ? r : ta.rows - 1;
+                c = c < ta.cols ? c : ta.cols - 1;
+            }
+            int64_t off = (int64_t)inst * ta.st + (int64_t)r * ta.sr + (int64_t)c * ta.sc;
+            dst[m] = narrow(load_stored(ta, off, err), err);
+        }
+    }
+}
+// 16 cells of height-2 node j (rows 4*(j>>1).., cols 4*(j&1)..) in local Morton order
+template <bool PADDED, bool VEC>
+K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t c0, int j, int32_t (&dst)[16],
+                       int32_t& err) {
+    const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+    if (VEC) {
+        const int32_t* p = (const int32_t*)ta.base + (int64_t)inst * ta.st + (int64_t)rj * ta.sr + cj;
+#pragma unroll
+        for (int dr = 0; dr < 4; dr++) {
+            const int32_t* q = p + (int64_t)dr * ta.sr;
+            int32_t v[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int4 a = *(const int4*)q;
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+#else
+            for (int i = 0; i < 4; i++) v[i] = q[i];
+#endif
+#pragma unroll
+            for (int dc = 0; dc < 4; dc++) dst[cell_m(dr, dc)] = v[dc];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            uint32_t r = rj + m_dr(m), c = cj + m_dc(m);
+            if (PADDED) {
+                r = r < ta.rows ? r : ta.rows - 1;
+                c = c < ta.cols ? c : ta.cols - 1;
+            }
+            int64_t off = (int64_t)inst * ta.st + (int64_t)r * ta.sr + (int64_t)c * ta.sc;
+            dst[m] = narrow(load_stored(ta, off, err), err);
+        }
+    }
+}
+
+// ---- sizes --------------------------------------------------------------
+struct DacLayout {
+    uint32_t n[5];       // n[j] = # values with more than j bytes (n[0] = all); n[4] = 0
+    uint32_t nlev;       // dac.rs:124-128
+    uint32_t bm_off[4];  // byte offset of level j's BitMap, relative to the instant's first byte
+    uint32_t by_off[4];  // byte offset of level j's bytes
+    uint32_t end;        // first byte after the Dac
+};
+K2R_HD DacLayout dac_layout(uint32_t base, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3) {
+    DacLayout L;
+    L.n[0] = n0; L.n[1] = n1; L.n[2] = n2; L.n[3] = n3; L.n[4] = 0;
+    L.nlev = 0;
+    uint32_t off = base + 1;  // n_levels byte (dac.rs:38)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        L.bm_off[j] = off;
+        L.by_off[j] = off;
+        if (L.n[j] > 0 && L.nlev == (uint32_t)j) {
+            L.nlev = j + 1;
+            off += bitmap_size(L.n[j]);
+            L.by_off[j] = off;
+            off += L.n[j];
+        }
+    }
+    L.end = off;
+    return L;
+}
+
+template <class C>
+struct Totals {
+    uint32_t Ni[C::H + 2];    // internal nodes per height (index 1..H)
+    uint32_t offV[C::H + 2];  // Lmax/T index of the first node of height h
+    uint32_t offI[C::H + 2];  // Lmin index of the first internal node of height h
+    uint32_t offZ[C::H + 2];  // eqB index of the first T=0 node of height h
+    uint32_t LT, N0, M0;
+    K2R_HD void from(uint64_t lo, uint64_t top) {
+        constexpr int H = C::H;
+        for (int h = 1; h <= H; h++) Ni[h] = unpackI(h, lo, top);
+        Ni[H + 1] = 0;
+        uint32_t v = 0, i = 0, z = 0;
+        for (int h = H; h >= 0; h--) {
+            uint32_t nv = (h == H) ? 1u : 4u * Ni[h + 1];
+            offV[h] = v;
+            offI[h] = i;
+            offZ[h] = z;
+            v += nv;
+            if (h >= 1) {
+                i += Ni[h];
+                z += nv - Ni[h];
+            }
+        }
+        N0 = v;
+        LT = offV[0];
+        M0 = i;
+    }
+};
+
+// ---- LDS bitmap helpers -------------------------------------------------------------------------
+// bit p lives in word p/32 at position 31-(p%32)  (bitmap.rs:176-183)
+template <class EX>
+K2R_HD void bm_set(EX& ex, uint32_t* bm, uint32_t p) {
+    ex.lds_or(&bm[p >> 5], 0x80000000u >> (p & 31));
+}
+// OR a run of `len` (1..32) bits starting at bit position p; bits are right-aligned in `bits`,
+// first bit of the run is the most significant of the len bits.
+template <class EX>
+K2R_HD void bm_or_run(EX& ex, uint32_t* bm, uint32_t p, uint32_t len, uint32_t bits) {
+    if (len == 0 || bits == 0) return;
+    const uint64_t v = (uint64_t)bits << (64 - len);  // left-aligned in 64
+    const uint32_t sh = p & 31;
+    const uint64_t w = v >> sh;  // occupies bits of words (p>>5) and (p>>5)+1
+    const uint32_t hi = (uint32_t)(w >> 32), lo = (uint32_t)w;
+    if (hi) ex.lds_or(&bm[p >> 5], hi);
+    if (lo) ex.lds_or(&bm[(p >> 5) + 1], lo);
+}
+// rank1 over [0,p) using per-word exclusive prefix popcounts
+K2R_HD uint32_t bm_rank(const uint32_t* bm, const uint32_t* pref, uint32_t p) {
+    const uint32_t w = p >> 5, b = p & 31;
+    uint32_t r = pref[w];
+    if (b) r += popc32(bm[w] >> (32 - b));
+    return r;
+}
+
+// Computes per-word exclusive popcount prefixes of an LDS bitmap (pref[0..W], pref[W] = total) and
+// writes the serialized BitMap (bitmap.rs:128-138) to `dst`.
+template <class C, class EX>
+K2R_HD void bitmap_finish_write(EX& ex, const uint32_t* bm, uint32_t nbits, uint32_t* pref, uint8_t* dst) {
+    constexpr int NT = C::NT;
+    const uint32_t W = (nbits + 31) / 32;
+    const uint32_t CH = (W + NT - 1) / NT;  // words per thread
+    ex.par_nosync([&](int tid, EncRegs& r) {
+        uint32_t s = 0;
+        const uint32_t w0 = (uint32_t)tid * CH;
+        for (uint32_t w = w0; w < w0 + CH && w < W; w++) s += popc32(bm[w]);
+        r.sc[0] = s;
+    });
+    ex.template scan<1>();
+    ex.par([&](int tid, EncRegs& r) {
+        uint32_t run = (uint32_t)r.sc[0];
+        const uint32_t w0 = (uint32_t)tid * CH;
+        for (uint32_t w = w0; w < w0 + CH && w < W; w++) {
+            pref[w] = run;
+            run += popc32(bm[w]);
+        }
+        if (tid == 0) pref[W] = (uint32_t)ex.sh.tot[0];
+    });
+    ex.par([&](int tid, EncRegs&) {
+        const uint32_t nidx = nbits / 128;  // bitmap.rs:70
+        if (tid == 0) {
+            store_be32(dst, nbits);
+            store_be32(dst + 4, 4u);  // k, bitmap.rs:69,130
+        }
+        for (uint32_t b = (uint32_t)tid; b < nidx; b += NT) store_be32(dst + 8 + 4 * b, pref[4 * (b + 1)]);
+        uint8_t* wd = dst + 8 + 4 * nidx;
+        for (uint32_t w = (uint32_t)tid; w < W; w += NT) store_be32(wd + 4 * w, bm[w]);
+    });
+}
+
+// ---- emission sink ---------------------------------------------------------------------------------
+// One Dac being written: plane-0 bytes go straight to memory, longer values go to the overflow list.
+struct DacSink {
+    uint8_t* plane0;   // where byte 0 of value #pos goes
+    uint32_t* bm0;     // LDS continuation bitmap of plane 0
+    uint64_t* list;    // overflow entries (pos << 32 | remaining bytes)
+    uint32_t* nlist;   // LDS counter
+};
+template <class EX>
+K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz) {
+    d.plane0[pos] = (uint8_t)zz;
+    if (zz > 0xffu) {
+        bm_set(ex, d.bm0, pos);
+        const uint32_t slot = ex.lds_add(d.nlist, 1u);
+        d.list[slot] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
+    }
+}
+
+// Planes 1..nlev-1 of one Dac from its overflow list; also writes every level's BitMap.
+// bmA = continuation bitmap of plane 0 (already complete), bmB = scratch for the next plane.
+template <class C, class EX>
+K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* bmA, uint32_t* bmB, uint32_t* pref,
+                       uint64_t* list, const uint32_t* nlist_p) {
+    constexpr int NT = C::NT;
+    uint32_t* cur = bmA;
+    uint32_t* nxt = bmB;
+    for (uint32_t j = 0; j < L.nlev; j++) {
+        bitmap_finish_write<C>(ex, cur, L.n[j], pref, inst_out + L.bm_off[j]);
+        if (j + 1 >= L.nlev) break;
+        const uint32_t Wn = (L.n[j + 1] + 31) / 32;
+        ex.par([&](int tid, EncRegs&) {
+            for (uint32_t w = (uint32_t)tid; w <= Wn; w += NT) nxt[w] = 0;
+        });
+        const uint32_t nl = *nlist_p;
+        uint8_t* plane = inst_out + L.by_off[j + 1];
+        ex.par([&](int tid, EncRegs&) {
+            for (uint32_t e = (uint32_t)tid; e < nl; e += NT) {
+                const uint64_t ent = list[e];
+                const uint32_t rem = (uint32_t)ent;
+                if (rem == 0) continue;  // value ended on an earlier plane
+                const uint32_t pos = (uint32_t)(ent >> 32);
+                const uint32_t q = bm_rank(cur, pref, pos);  // dac.rs:86
+                plane[q] = (uint8_t)rem;
+                const uint32_t rest = rem >> 8;
+                if (rest) bm_set(ex, nxt, q);
+                list[e] = ((uint64_t)q << 32) | (uint64_t)rest;
+            }
+        });
+        uint32_t* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+}
+
+// ======================================================================================================
+// The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 input,
+// unit column stride, 16-byte aligned rows (=> vector loads), implies !PADDED.
+// ======================================================================================================
+template <class C, bool PADDED, bool VEC, class EX>
+K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM) {
+    constexpr int H = C::H;
+    constexpr int NT = C::NT;
+    auto& sh = ex.sh;
+    static_assert(!(PADDED && VEC), "vector loads need an unpadded tile");
+
+    uint8_t* const out = ta.out;
+    const uint64_t cap = ta.out_cap;
+
+    // ---- geometry of an in-thread / top node ---------------------------------------------------------
+    auto blk_origin = [&](int tid, uint32_t& r0, uint32_t& c0) {
+        uint32_t br, bc;
+        morton_decode((uint32_t)tid, br, bc);
+        r0 = br * 8;
+        c0 = bc * 8;
+    };
+    // all-invalid test of the node whose top-left cell is (r,c)  (snapshot.rs:453-457)
+    auto inval = [&](uint32_t r, uint32_t c) -> bool { return PADDED && (r >= ta.rows || c >= ta.cols); };
+    auto top_inval = [&](int h, uint32_t j) -> bool {
+        if (!PADDED) return false;
+        uint32_t br, bc;
+        morton_decode(j, br, bc);
+        return inval(br << h, bc << h);
+    };
+
+    uint32_t off = 6;            // chunk header: encoding, fractional_bits, n_blocks (chunk.rs:236-238)
+    uint32_t n_blocks = 0;
+    uint32_t blk_hdr = 6;        // where the open block's n_instants byte goes (block.rs:89)
+    uint32_t blk_count = 0;      // instants in the open block
+    uint32_t s_idx = 0;          // instant of the open block's snapshot (chunk.rs:52)
+    uint32_t n_snap = 0, n_log = 0;
+    int32_t status = ST_OK;
+
+    ex.par([&](int tid, EncRegs&) {
+        if (tid == 0) {
+            sh.err = 0;
+            if (cap >= 6) {
+                out[0] = (uint8_t)ta.dtype;
+                out[1] = (uint8_t)ta.fbits;
+            }
+        }
+    });
+    if (cap < 7) status = ST_OUT_CAPACITY;
+
+    for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
+        const bool have_s = inst > 0;
+
+        // ================= phase 1: load, thread-local pyramids, thread-local counts =================
+        ex.par([&](int tid, EncRegs& r) {
+            uint32_t r0, c0;
+            blk_origin(tid, r0, c0);
+            int32_t err = 0;
+            load_block<PADDED, VEC>(ta, inst, r0, c0, r.t, err);
+
+            // ---- snapshot candidate (snapshot.rs:108-156) ----
+            int32_t mn1[16], mx1[16], mn2[4], mx2[4];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                mn1[q] = min4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
+                mx1[q] = max4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                mn2[j] = min4(mn1[4 * j], mn1[4 * j + 1], mn1[4 * j + 2], mn1[4 * j + 3]);
+                mx2[j] = max4(mx1[4 * j], mx1[4 * j + 1], mx1[4 * j + 2], mx1[4 * j + 3]);
+            }
+            const int32_t mn3 = min4(mn2[0], mn2[1], mn2[2], mn2[3]);
+            const int32_t mx3 = max4(mx2[0], mx2[1], mx2[2], mx2[3]);
+            const bool inv3 = inval(r0, c0);
+            const bool P3 = !inv3 && mn3 != mx3;
+
+            uint32_t sI1 = 0, sI2 = 0;
+            Cls sMax, sMin;
+            // every in-thread difference is bounded by mx3-mn3: below 128 they all fit one byte
+            const bool need_cls = PADDED || (mx3 - mn3) >= 128;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                const bool inv2 = inval(rj, cj);
+                const bool P2 = !inv2 && mn2[j] != mx2[j];
+                sI2 += P2 ? 1u : 0u;
+                if (need_cls) {
+                    sMax.add(zz32(inv2 ? mx3 : mx3 - mx2[j]), P3);
+                    sMin.add(zz32(mn2[j] - mn3), P2);
+                }
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const int q = 4 * j + qq;
+                    const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                    const bool inv1 = inval(rq, cq);
+                    const bool P1 = !inv1 && mn1[q] != mx1[q];
+                    sI1 += P1 ? 1u : 0u;
+                    if (need_cls) {
+                        sMax.add(zz32(inv1 ? mx2[j] : mx2[j] - mx1[q]), P2);
+                        sMin.add(zz32(mn1[q] - mn2[j]), P1);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
+                            sMax.add(zz32(inv0 ? mx1[q] : mx1[q] - r.t[4 * q + i]), P1);
+                        }
+                    }
+                }
+            }
+            sh.tmin[tid] = mn3;
+            sh.tmax[tid] = mx3;
+            r.sc[0] = (uint64_t)sI1 | ((uint64_t)sI2 << 16);
+            r.sc[2] = sMax.pack18();
+            r.sc[3] = sMin.pack16();
+
+            // ---- log candidate vs. the open block's snapshot (log.rs:112-165, 725-817) ----
+            uint32_t lI1 = 0, lI2 = 0;
+            Cls lMax, lMin;
+            if (have_s) {
+                int32_t smn2[4], smx2[4], df2[4];
+                bool eq2[4], P2v[4];
+                Cls pend2;  // classes of the height-2 Lmax values, valid iff P3 (known after the loop)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int32_t s16[16];
+                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
+                    const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                    int32_t smn1[4], smx1[4], df1[4];
+                    bool eq1[4], P1v[4];
+                    Cls pend1;  // classes of the four height-1 Lmax values, valid iff P2
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const int q = 4 * j + qq;
+                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                        const bool inv1 = inval(rq, cq);
+                        int32_t d[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
+                            d[i] = inv0 ? 0 : r.t[4 * q + i] - s16[4 * qq + i];  // log.rs:751
+                        }
+                        smn1[qq] = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                        smx1[qq] = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                        eq1[qq] = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];  // log.rs:780,805
+                        df1[qq] = d[0];
+                        P1v[qq] = !inv1 && mn1[q] != mx1[q] && !eq1[qq];  // log.rs:137-152
+                        lI1 += P1v[qq] ? 1u : 0u;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) lMax.add(zz32(d[i]), P1v[qq]);   // cells: t - s
+                        pend1.add(zz32(inv1 ? 0 : mx1[q] - smx1[qq]), true);         // log.rs:133
+                        lMin.add(zz32(mn1[q] - smn1[qq]), P1v[qq]);                  // log.rs:148
+                    }
+                    const bool inv2 = inval(rj, cj);
+                    smn2[j] = min4(smn1[0], smn1[1], smn1[2], smn1[3]);
+                    smx2[j] = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
+                    eq2[j] = eq1[0] && eq1[1] && eq1[2] && eq1[3] && df1[0] == df1[1] && df1[0] == df1[2] &&
+                             df1[0] == df1[3];
+                    df2[j] = df1[0];
+                    P2v[j] = !inv2 && mn2[j] != mx2[j] && !eq2[j];
+                    lI2 += P2v[j] ? 1u : 0u;
+                    lMax.add(pend1, P2v[j]);
+                    pend2.add(zz32(inv2 ? 0 : mx2[j] - smx2[j]), true);
+                    lMin.add(zz32(mn2[j] - smn2[j]), P2v[j]);
+                }
+                const int32_t smn3 = min4(smn2[0], smn2[1], smn2[2], smn2[3]);
+                const int32_t smx3 = max4(smx2[0], smx2[1], smx2[2], smx2[3]);
+                const bool eq3 = eq2[0] && eq2[1] && eq2[2] && eq2[3] && df2[0] == df2[1] && df2[0] == df2[2] &&
+                                 df2[0] == df2[3];
+                const bool PL3 = !inv3 && mn3 != mx3 && !eq3;
+                lMax.add(pend2, PL3);
+                sh.smin[tid] = smn3;
+                sh.smax[tid] = smx3;
+                sh.diff[tid] = df2[0];
+                sh.eq[tid] = eq3 ? 1u : 0u;
+            }
+            r.sc[4] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
+            r.sc[6] = lMax.pack18();
+            r.sc[7] = lMin.pack16();
+            if (err != 0) ex.lds_min(&sh.err, err);
+        });
+        if (sh.err != 0) {
+            status = sh.err == ERR_RANGE ? (int32_t)ST_UNSUPPORTED : sh.err;
+            break;
+        }
+
+        // ================= phase 2: heights 4..H in LDS (snapshot.rs:476-497, log.rs:776-806) ==========
+        for (int h = 4; h <= H; h++) {
+            const int n_h = 1 << (2 * (H - h));
+            const int co = C::top_off(h - 1), po = C::top_off(h);
+            ex.par([&](int tid, EncRegs&) {
+                for (int j = tid; j < n_h; j += NT) {
+                    const int c = co + 4 * j;
+                    sh.tmin[po + j] = min4(sh.tmin[c], sh.tmin[c + 1], sh.tmin[c + 2], sh.tmin[c + 3]);
+                    sh.tmax[po + j] = max4(sh.tmax[c], sh.tmax[c + 1], sh.tmax[c + 2], sh.tmax[c + 3]);
+                    if (have_s) {
+                        sh.smin[po + j] = min4(sh.smin[c], sh.smin[c + 1], sh.smin[c + 2], sh.smin[c + 3]);
+                        sh.smax[po + j] = max4(sh.smax[c], sh.smax[c + 1], sh.smax[c + 2], sh.smax[c + 3]);
+                        const int32_t d0 = sh.diff[c];
+                        sh.diff[po + j] = d0;
+                        sh.eq[po + j] = (sh.eq[c] & sh.eq[c + 1] & sh.eq[c + 2] & sh.eq[c + 3]) &&
+                                                d0 == sh.diff[c + 1] && d0 == sh.diff[c + 2] && d0 == sh.diff[c + 3]
+                                            ? 1u
+                                            : 0u;
+                    }
+                }
+            });
+        }
+
+        // node predicates on the top arrays (index = top_off(h) + j)
+        auto PS = [&](int h, uint32_t j) -> bool {
+            const int a = C::top_off(h) + (int)j;
+            return !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];
+        };
+        auto PL = [&](int h, uint32_t j) -> bool {
+            const int a = C::top_off(h) + (int)j;
+            return !top_inval(h, j) && sh.tmin[a] != sh.tmax[a] && sh.eq[a] == 0;
+        };
+        // Lmax / Lmin values of node (h,j), h >= 3 (root: absolute, snapshot.rs:123)
+        auto snap_vmax = [&](int h, uint32_t j) -> int32_t {
+            const int a = C::top_off(h) + (int)j;
+            if (h == H) return sh.tmax[a];
+            const int p = C::top_off(h + 1) + (int)(j >> 2);
+            return top_inval(h, j) ? sh.tmax[p] : sh.tmax[p] - sh.tmax[a];  // snapshot.rs:139
+        };
+        auto snap_vmin = [&](int h, uint32_t j) -> int32_t {
+            const int a = C::top_off(h) + (int)j;
+            if (h == H) return sh.tmin[a];
+            const int p = C::top_off(h + 1) + (int)(j >> 2);
+            return sh.tmin[a] - sh.tmin[p];  // snapshot.rs:140
+        };
+        auto log_vmax = [&](int h, uint32_t j) -> int32_t {
+            const int a = C::top_off(h) + (int)j;
+            return top_inval(h, j) ? 0 : sh.tmax[a] - sh.smax[a];  // log.rs:133
+        };
+        auto log_vmin = [&](int h, uint32_t j) -> int32_t {
+            const int a = C::top_off(h) + (int)j;
+            return sh.tmin[a] - sh.smin[a];  // log.rs:148
+        };
+
+        // ================= phase 3: own node + owned top nodes, then the scan ==========================
+        ex.par([&](int tid, EncRegs& r) {
+            uint64_t sLo = r.sc[0], sTop = 0, lLo = r.sc[4], lTop = 0;
+            Cls sMax, sMin, lMax, lMin;
+            for (int h = 3; h <= H; h++) {
+                const uint32_t span = 1u << (2 * (h - 3));  // threads under one node of height h
+                if (((uint32_t)tid & (span - 1)) != 0) break;
+                const uint32_t j = (uint32_t)tid >> (2 * (h - 3));
+                const bool visS = (h == H) ? true : PS(h + 1, j >> 2);
+                const bool pS = PS(h, j);
+                sMax.add(zz32(snap_vmax(h, j)), visS);
+                sMin.add(zz32(snap_vmin(h, j)), pS);
+                if (pS) {
+                    if (h == 3) sLo += 1ull << 30;
+                    else sTop += packTop(h);
+                }
+                if (have_s) {
+                    const bool visL = (h == H) ? true : PL(h + 1, j >> 2);
+                    const bool pL = PL(h, j);
+                    lMax.add(zz32(log_vmax(h, j)), visL);
+                    lMin.add(zz32(log_vmin(h, j)), pL);
+                    if (pL) {
+                        if (h == 3) lLo += 1ull << 30;
+                        else lTop += packTop(h);
+                    }
+                }
+            }
+            r.sc[0] = sLo;
+            r.sc[1] = sTop;
+            r.sc[2] += sMax.pack18();
+            r.sc[3] += sMin.pack16();
+            r.sc[4] = lLo;
+            r.sc[5] = lTop;
+            r.sc[6] += lMax.pack18();
+            r.sc[7] += lMin.pack16();
+        });
+        ex.template scan<8>();
+
+        // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
+        Totals<C> TS, TL;
+        TS.from(sh.tot[0], sh.tot[1]);
+        const uint64_t sx = sh.tot[2], sn = sh.tot[3];
+        const DacLayout SV = dac_layout(13 + bitmap_size(TS.LT), TS.N0, (uint32_t)(sx & 0x3ffff),
+                                        (uint32_t)((sx >> 18) & 0x3ffff), (uint32_t)((sx >> 36) & 0x3ffff));
+        const DacLayout SM = dac_layout(SV.end, TS.M0, (uint32_t)(sn & 0xffff), (uint32_t)((sn >> 16) & 0xffff),
+                                        (uint32_t)((sn >> 32) & 0xffff));
+        const uint32_t snap_size = SM.end;  // snapshot.rs:87-92
+        DacLayout LV = SV, LM = SM;
+        uint32_t log_size = 0, log_eq_off = 0;
+        if (have_s) {
+            TL.from(sh.tot[4], sh.tot[5]);
+            const uint64_t lx = sh.tot[6], ln = sh.tot[7];
+            log_eq_off = 13 + bitmap_size(TL.LT);
+            LV = dac_layout(log_eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, (uint32_t)(lx & 0x3ffff),
+                            (uint32_t)((lx >> 18) & 0x3ffff), (uint32_t)((lx >> 36) & 0x3ffff));
+            LM = dac_layout(LV.end, TL.M0, (uint32_t)(ln & 0xffff), (uint32_t)((ln >> 16) & 0xffff),
+                            (uint32_t)((ln >> 32) & 0xffff));
+            log_size = LM.end;  // log.rs:95-97
+        }
+        const bool as_snapshot = !have_s || (blk_count - 1 == 254) || snap_size <= log_size;
+
+        uint32_t hdr_patch_off = 0, hdr_patch_val = 0;
+        bool do_patch = false;
+        if (as_snapshot) {
+            if (have_s) {  // close the open block (chunk.rs:63-70)
+                do_patch = true;
+                hdr_patch_off = blk_hdr;
+                hdr_patch_val = blk_count;
+                n_blocks++;
+            }
+            blk_hdr = off;
+            off += 1;
+            blk_count = 0;
+            s_idx = inst;
+            n_snap++;
+        } else {
+            n_log++;
+        }
+        const uint32_t isize = as_snapshot ? snap_size : log_size;
+        if ((uint64_t)off + isize > cap) {
+            status = ST_OUT_CAPACITY;
+            break;
+        }
+        uint8_t* const io = out + off;  // first byte of this Snapshot / Log
+        const Totals<C>& TT = as_snapshot ? TS : TL;
+        const DacLayout& DV = as_snapshot ? SV : LV;
+        const DacLayout& DM = as_snapshot ? SM : LM;
+
+        // ================= phase 5: emission of the winner ===============================================
+        // 5a. clear bitmaps, save prefixes, header
+        const uint32_t WTn = (TT.LT + 31) / 32, WVn = (TT.N0 + 31) / 32, WMn = (TT.M0 + 31) / 32;
+        ex.par([&](int tid, EncRegs& r) {
+            for (uint32_t w = (uint32_t)tid; w <= WTn; w += NT) {
+                sh.bmT[w] = 0;
+                sh.bmE[w] = 0;
+            }
+            for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV[0][w] = 0;
+            for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
+            r.pf_lo = as_snapshot ? r.sc[0] : r.sc[4];
+            r.pf_top = as_snapshot ? r.sc[1] : r.sc[5];
+            if (tid == 0) {
+                sh.nlistV = 0;
+                sh.nlistM = 0;
+                if (do_patch) out[hdr_patch_off] = (uint8_t)hdr_patch_val;
+                io[0] = 2;  // k  (snapshot.rs:49, log.rs:54)
+                store_be32(io + 1, ta.rows);
+                store_be32(io + 5, ta.cols);
+                store_be32(io + 9, (uint32_t)C::S);
+                io[DV.bm_off[0] - 1] = (uint8_t)DV.nlev;  // dac.rs:38
+                io[DM.bm_off[0] - 1] = (uint8_t)DM.nlev;
+                if (ta.minmax) {
+                    ta.minmax[2 * inst] = sh.tmin[C::top_off(H)];
+                    ta.minmax[2 * inst + 1] = sh.tmax[C::top_off(H)];
+                }
+            }
+        });
+
+        const DacSink sinkV{io + DV.by_off[0], sh.bmV[0], listV, &sh.nlistV};
+        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM};
+
+        // 5b. plane 0 of both Dacs, T (and eqB) bits
+        ex.par([&](int tid, EncRegs& r) {
+            uint32_t r0, c0;
+            blk_origin(tid, r0, c0);
+            const uint64_t pLo = r.pf_lo, pTop = r.pf_top;
+
+            // -- top nodes owned by this thread, and its own height-3 node --
+            for (int h = 3; h <= H; h++) {
+                const uint32_t span = 1u << (2 * (h - 3));
+                if (((uint32_t)tid & (span - 1)) != 0) break;
+                const uint32_t j = (uint32_t)tid >> (2 * (h - 3));
+                const bool vis = (h == H) ? true : (as_snapshot ? PS(h + 1, j >> 2) : PL(h + 1, j >> 2));
+                if (!vis) continue;
+                const bool p = as_snapshot ? PS(h, j) : PL(h, j);
+                // rank of the parent among internal nodes of height h+1: the exclusive prefix of this
+                // thread counts the parent itself unless this thread owns it (j & 3 == 0)
+                uint32_t vrank = 0;
+                if (h < H) vrank = 4 * (unpackI(h + 1, pLo, pTop) - ((j & 3) ? 1u : 0u)) + (j & 3);
+                const uint32_t idx = TT.offV[h] + vrank;
+                const uint32_t irank = unpackI(h, pLo, pTop);
+                emit_val(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)));
+                if (p) {
+                    bm_set(ex, sh.bmT, idx);
+                    emit_val(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)));
+                } else if (!as_snapshot) {
+                    const int a = C::top_off(h) + (int)j;
+                    const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
+                    if (e) bm_set(ex, sh.bmE, TT.offZ[h] + vrank - irank);
+                }
+            }
+
+            // -- in-thread heights 2,1,0 --
+            int32_t mn1[16], mx1[16], mn2[4], mx2[4];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                mn1[q] = min4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
+                mx1[q] = max4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                mn2[j] = min4(mn1[4 * j], mn1[4 * j + 1], mn1[4 * j + 2], mn1[4 * j + 3]);
+                mx2[j] = max4(mx1[4 * j], mx1[4 * j + 1], mx1[4 * j + 2], mx1[4 * j + 3]);
+            }
+            const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
+            const bool inv3 = inval(r0, c0);
+            const uint32_t E1 = unpackI(1, pLo, pTop), E2 = unpackI(2, pLo, pTop), E3 = unpackI(3, pLo, pTop);
+
+            if (as_snapshot) {
+                const bool P3 = !inv3 && mn3 != mx3;
+                if (P3) {
+                    uint32_t p2 = TT.offV[2] + 4 * E3;  // my four height-2 nodes
+                    uint32_t p1 = TT.offV[1] + 4 * E2;  // running: my visited height-1 nodes
+                    uint32_t p0 = TT.offV[0] + 4 * E1;  // running: my visited cells
+                    uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
+                    uint32_t tb2 = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                        const bool inv2 = inval(rj, cj);
+                        const bool P2 = !inv2 && mn2[j] != mx2[j];
+                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? mx3 : mx3 - mx2[j]));
+                        tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
+                        if (P2) {
+                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - mn3));
+                            uint32_t tb1 = 0;
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++) {
+                                const int q = 4 * j + qq;
+                                const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                                const bool inv1 = inval(rq, cq);
+                                const bool P1 = !inv1 && mn1[q] != mx1[q];
+                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? mx2[j] : mx2[j] - mx1[q]));
+                                tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
+                                if (P1) {
+                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - mn2[j]));
+#pragma unroll
+                                    for (int i = 0; i < 4; i++) {
+                                        const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
+                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? mx1[q] : mx1[q] - r.t[4 * q + i]));
+                                    }
+                                    p0 += 4;
+                                }
+                            }
+                            bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                            p1 += 4;
+                        }
+                    }
+                    bm_or_run(ex, sh.bmT, p2, 4, tb2);
+                }
+            } else {
+                // log: needs the snapshot's cells again (served from L2 / Infinity Cache)
+                int32_t err = 0;
+                int32_t s64[64];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int32_t s16[16];
+                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
+#pragma unroll
+                    for (int m = 0; m < 16; m++) s64[16 * j + m] = s16[m];
+                }
+                int32_t smn1[16], smx1[16], smn2[4], smx2[4], df1[16], df2[4];
+                bool eq1[16], eq2[4];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t rq = r0 + 4 * ((q >> 2) >> 1) + 2 * ((q & 3) >> 1);
+                    const uint32_t cq = c0 + 4 * ((q >> 2) & 1) + 2 * ((q & 3) & 1);
+                    int32_t d[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : r.t[4 * q + i] - s64[4 * q + i];
+                    smn1[q] = min4(s64[4 * q], s64[4 * q + 1], s64[4 * q + 2], s64[4 * q + 3]);
+                    smx1[q] = max4(s64[4 * q], s64[4 * q + 1], s64[4 * q + 2], s64[4 * q + 3]);
+                    eq1[q] = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
+                    df1[q] = d[0];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    smn2[j] = min4(smn1[4 * j], smn1[4 * j + 1], smn1[4 * j + 2], smn1[4 * j + 3]);
+                    smx2[j] = max4(smx1[4 * j], smx1[4 * j + 1], smx1[4 * j + 2], smx1[4 * j + 3]);
+                    eq2[j] = eq1[4 * j] && eq1[4 * j + 1] && eq1[4 * j + 2] && eq1[4 * j + 3] &&
+                             df1[4 * j] == df1[4 * j + 1] && df1[4 * j] == df1[4 * j + 2] &&
+                             df1[4 * j] == df1[4 * j + 3];
+                    df2[j] = df1[4 * j];
+                }
+                const bool PL3 = !inv3 && mn3 != mx3 && sh.eq[tid] == 0;
+                if (PL3) {
+                    uint32_t p2 = TT.offV[2] + 4 * E3, p1 = TT.offV[1] + 4 * E2, p0 = TT.offV[0] + 4 * E1;
+                    uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
+                    uint32_t z2 = TT.offZ[2] + 4 * E3 - E2, z1 = TT.offZ[1] + 4 * E2 - E1;
+                    uint32_t tb2 = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                        const bool inv2 = inval(rj, cj);
+                        const bool unif2 = inv2 || mn2[j] == mx2[j];
+                        const bool P2 = !unif2 && !eq2[j];
+                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? 0 : mx2[j] - smx2[j]));
+                        tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
+                        if (!P2) {
+                            if (!unif2) bm_set(ex, sh.bmE, z2);  // equal, log.rs:141-144
+                            z2++;
+                        } else {
+                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - smn2[j]));
+                            uint32_t tb1 = 0;
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++) {
+                                const int q = 4 * j + qq;
+                                const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                                const bool inv1 = inval(rq, cq);
+                                const bool unif1 = inv1 || mn1[q] == mx1[q];
+                                const bool P1 = !unif1 && !eq1[q];
+                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? 0 : mx1[q] - smx1[q]));
+                                tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
+                                if (!P1) {
+                                    if (!unif1) bm_set(ex, sh.bmE, z1);
+                                    z1++;
+                                } else {
+                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - smn1[q]));
+#pragma unroll
+                                    for (int i = 0; i < 4; i++) {
+                                        const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
+                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? 0 : r.t[4 * q + i] - s64[4 * q + i]));
+                                    }
+                                    p0 += 4;
+                                }
+                            }
+                            bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                            p1 += 4;
+                        }
+                    }
+                    bm_or_run(ex, sh.bmT, p2, 4, tb2);
+                }
+            }
+        });
+
+        // 5c. bitmaps + higher planes
+        bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
+        if (!as_snapshot) bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
+        dac_finish<C>(ex, DV, io, sh.bmV[0], sh.bmV[1], sh.prefV, listV, &sh.nlistV);
+        dac_finish<C>(ex, DM, io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
+
+        off += isize;
+        blk_count++;
+    }
+
+    // ---- close the last block, chunk header (chunk.rs:76-78, 238) ----
+    ex.par([&](int tid, EncRegs&) {
+        if (tid == 0) {
+            if (status == ST_OK) {
+                out[blk_hdr] = (uint8_t)blk_count;
+                store_be32(out + 2, n_blocks + 1);
+            }
+            res->status = status;
+            res->snapshots = n_snap;
+            res->logs = n_log;
+            res->len = status == ST_OK ? off : 0;
+        }
+    });
+}
+
+}  // namespace k2r

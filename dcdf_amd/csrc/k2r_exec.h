@@ -1,0 +1,139 @@
+// k2r_exec.h -- execution contexts for the bulk-synchronous kernel bodies.
+//
+// A kernel body is a sequence of phases.  `ex.par(f)` runs f(tid, regs) for every
+// thread of the workgroup and ends with a workgroup barrier; code between phases is
+// wave-uniform and may only READ shared state.  `ex.scan<NF>()` is a workgroup
+// exclusive prefix sum over the per-thread fields regs.sc[0..NF) that also leaves
+// the totals in shared.tot[].
+//
+//   GpuExec : the gfx950 context (one HIP thread per logical thread; wave64 shuffles + LDS).
+//   SimExec : sequential host context, compiled ONLY by tests/sim (see k2r_common.h).
+#pragma once
+#include "k2r_common.h"
+
+namespace k2r {
+
+constexpr int MAX_SCAN_FIELDS = 8;
+
+#if defined(__HIPCC__)
+
+template <class SH, class TR, int NT>
+struct GpuExec {
+    SH& sh;
+    TR r;
+    const int tid;
+    static constexpr int kNT = NT;
+    static constexpr bool kSim = false;
+
+    __device__ GpuExec(SH& s) : sh(s), tid((int)threadIdx.x) {}
+
+    template <class F>
+    __device__ __forceinline__ void par(F&& f) {
+        f(tid, r);
+        __syncthreads();
+    }
+    // phase without trailing barrier (caller guarantees no hazard before the next barrier)
+    template <class F>
+    __device__ __forceinline__ void par_nosync(F&& f) {
+        f(tid, r);
+    }
+    __device__ __forceinline__ void barrier() { __syncthreads(); }
+
+    __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+    __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ int32_t lds_min(int32_t* p, int32_t v) { return atomicMin(p, v); }
+
+    // workgroup exclusive scan of r.sc[0..NF); totals -> sh.tot[0..NF)
+    template <int NF>
+    __device__ __forceinline__ void scan() {
+        constexpr int W = NT < 64 ? NT : 64;    // active lanes per wave
+        constexpr int NW = NT < 64 ? 1 : NT / 64;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        uint64_t incl[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            uint64_t v = r.sc[f];
+#pragma unroll
+            for (int d = 1; d < W; d <<= 1) {
+                uint64_t o = __shfl_up((unsigned long long)v, (unsigned)d, 64);
+                if (lane >= d) v += o;
+            }
+            incl[f] = v;
+            if (lane == W - 1) sh.wsum[wave][f] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            uint64_t base = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                uint64_t s = sh.wsum[w][f];
+                if (w < wave) base += s;
+                tot += s;
+            }
+            r.sc[f] = base + incl[f] - r.sc[f];
+            if (tid == 0) sh.tot[f] = tot;
+        }
+        __syncthreads();
+    }
+};
+
+#endif  // __HIPCC__
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+}  // namespace k2r
+#include <vector>
+namespace k2r {
+
+template <class SH, class TR, int NT>
+struct SimExec {
+    SH& sh;
+    std::vector<TR> regs;
+    static constexpr int kNT = NT;
+    static constexpr bool kSim = true;
+
+    explicit SimExec(SH& s) : sh(s), regs(NT) {}
+
+    template <class F>
+    void par(F&& f) {
+        for (int t = 0; t < NT; t++) f(t, regs[t]);
+    }
+    template <class F>
+    void par_nosync(F&& f) {
+        for (int t = 0; t < NT; t++) f(t, regs[t]);
+    }
+    void barrier() {}
+
+    uint32_t lds_or(uint32_t* p, uint32_t v) {
+        uint32_t o = *p;
+        *p = o | v;
+        return o;
+    }
+    uint32_t lds_add(uint32_t* p, uint32_t v) {
+        uint32_t o = *p;
+        *p = o + v;
+        return o;
+    }
+    int32_t lds_min(int32_t* p, int32_t v) {
+        int32_t o = *p;
+        if (v < o) *p = v;
+        return o;
+    }
+
+    template <int NF>
+    void scan() {
+        for (int f = 0; f < NF; f++) {
+            uint64_t run = 0;
+            for (int t = 0; t < NT; t++) {
+                uint64_t v = regs[t].sc[f];
+                regs[t].sc[f] = run;
+                run += v;
+            }
+            sh.tot[f] = run;
+        }
+    }
+};
+#endif
+
+}  // namespace k2r

@@ -1,0 +1,31 @@
+// k2r_launch.h -- host-side launch descriptors shared by k2r_kernels.hip and the C-ABI runtime.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "k2r_common.h"
+
+namespace k2r {
+
+struct EncClass {  // one kernel instantiation
+    int log2s;     // 3..8
+    bool padded;
+    bool vec;
+    bool operator==(const EncClass& o) const { return log2s == o.log2s && padded == o.padded && vec == o.vec; }
+};
+
+struct EncodeLaunch {
+    const TileArgs* tiles;  // device
+    TileResult* results;    // device
+    const uint32_t* order;  // device: tile indices of this class
+    uint32_t n;             // tiles in this class
+    uint32_t* queue;        // device: zeroed work counter
+    uint64_t* lists;        // device: grid * encode_list_words(cls) u64
+    uint32_t grid;
+};
+
+hipError_t launch_encode(const EncClass& cls, const EncodeLaunch& L, hipStream_t stream);
+int encode_blocks_per_cu(const EncClass& cls);
+size_t encode_list_words(const EncClass& cls);
+int encode_threads(const EncClass& cls);
+
+}  // namespace k2r

@@ -1,0 +1,67 @@
+// k2r_runtime.h -- host runtime shared by the C-ABI translation units (device discovery, error mapping).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/dcdf_k2r.h"
+#include "k2r_common.h"
+
+namespace k2r {
+
+struct Runtime {
+    bool ok = false;
+    int device = 0;
+    int cus = 0;
+    std::string name;
+    static Runtime& get();  // lazily initialised; ok == false when no usable device
+};
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        else p = nullptr;
+        return e;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+inline int map_status(int32_t st) {
+    switch (st) {
+        case ST_OK: return DCDF_OK;
+        case ST_NONFINITE: return DCDF_ERR_NONFINITE;
+        case ST_PRECISION: return DCDF_ERR_PRECISION;
+        case ST_OVERFLOW: return DCDF_ERR_OVERFLOW;
+        case ST_UNSUPPORTED: return DCDF_ERR_UNSUPPORTED;
+        case ST_BAD_ARG: return DCDF_ERR_BAD_ARG;
+        default: return DCDF_ERR_NO_DEVICE;
+    }
+}
+
+#define K2R_HIP(call)                                  \
+    do {                                               \
+        hipError_t _e = (call);                        \
+        if (_e != hipSuccess) {                        \
+            if (_e == hipErrorOutOfMemory) return DCDF_ERR_NOMEM; \
+            return DCDF_ERR_NO_DEVICE;                 \
+        }                                              \
+    } while (0)
+
+}  // namespace k2r

@@ -1,0 +1,64 @@
+"""Device-resident encode session (dcdf_encoder_* of include/dcdf_k2r.h): tiles already in HBM,
+encoded bytes stay in HBM.  Used by bench.py and the full-size GPU tests."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Encoder:
+    def __init__(self, descs, k=2, out_cap_per_tile=0):
+        """descs: list of (device_ptr, dtype_code, (st, sr, sc), (instants, rows, cols))"""
+        n = len(descs)
+        self.n = n
+        self._descs = (L.TileDesc * n)()
+        for i, (ptr, dt, st, shp) in enumerate(descs):
+            d = self._descs[i]
+            d.base = ptr
+            d.dtype = dt
+            d.stride_t, d.stride_r, d.stride_c = st
+            d.instants, d.rows, d.cols = shp
+        self._h = C.c_void_p()
+        L.check(L.lib().dcdf_encoder_create(self._descs, C.c_size_t(n), int(k), C.c_size_t(out_cap_per_tile),
+                                            C.byref(self._h)), "encoder_create")
+
+    def run(self):
+        ms = C.c_float()
+        L.check(L.lib().dcdf_encoder_run(self._h, C.byref(ms)), "encoder_run")
+        return ms.value
+
+    def result(self, i):
+        st, ln, ns, nl = C.c_int32(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        L.check(L.lib().dcdf_encoder_result(self._h, C.c_size_t(i), C.byref(st), C.byref(ln), C.byref(ns), C.byref(nl), None))
+        return st.value, ln.value, ns.value, nl.value
+
+    def fetch(self, i):
+        st, ln, _, _ = self.result(i)
+        if st != 0:
+            raise L.DcdfError(st, "tile %d" % i)
+        buf = np.zeros(ln, dtype=np.uint8)
+        L.check(L.lib().dcdf_encoder_fetch(self._h, C.c_size_t(i), C.c_void_p(buf.ctypes.data), C.c_size_t(ln)))
+        return buf.tobytes()
+
+    def total_bytes(self):
+        return int(L.lib().dcdf_encoder_total_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().dcdf_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth_fill(dev_ptr, dtype_code, seed, t0, t1, r0, r1, c0, c1):
+    from . import synth
+    tab = np.ascontiguousarray(synth._COS.astype(np.int32))
+    L.check(L.lib().dcdf_synth_fill(C.c_void_p(dev_ptr), C.c_int32(dtype_code), C.c_uint64(seed), C.c_int64(t0),
+                                    C.c_int64(t1), C.c_int64(r0), C.c_int64(r1), C.c_int64(c0), C.c_int64(c1),
+                                    C.c_void_p(tab.ctypes.data)), "synth_fill")

@@ -1,0 +1,160 @@
+/* dcdf_k2r.h -- C ABI of the MI355X-native Heuristic K^2-Raster chunk engine.
+ *
+ * Drop-in boundary for ONE path of Arbol-Project/dcdf v0.2.0: `Chunk::build` and the
+ * chunk-level queries.  Every entry point names the reference interface it replaces
+ * (file:line relative to /root/reference/dcdf/src/).  A Rust `dcdf` fork binds these
+ * with a plain `extern "C"` block; nothing here mentions torch.
+ *
+ * All encoded byte strings are bit-identical to the reference's `Chunk::write_to`
+ * (chunk.rs:235-243).  Panics of the reference are negative return codes here.
+ * The library needs a gfx950 GPU: every compute entry point returns
+ * DCDF_ERR_NO_DEVICE when none is present -- there is no CPU fallback.
+ */
+#ifndef DCDF_K2R_H
+#define DCDF_K2R_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MMEncoding byte codes, mmstruct.rs:36-43 */
+enum { DCDF_I32 = 4, DCDF_I64 = 8, DCDF_F32 = 32, DCDF_F64 = 64 };
+
+/* memory space of caller-owned buffers */
+enum { DCDF_MEM_HOST = 0, DCDF_MEM_DEVICE = 1 };
+
+/* return / status codes (0 = ok) */
+enum {
+    DCDF_OK = 0,
+    DCDF_ERR_BAD_ARG = -1,       /* instants == 0, bad dtype, null pointer ...                     */
+    DCDF_ERR_NONFINITE = -2,     /* to_fixed on +-inf                       fixed.rs:39-41         */
+    DCDF_ERR_PRECISION = -3,     /* to_fixed precision loss, round=false    fixed.rs:47-59         */
+    DCDF_ERR_OVERFLOW = -4,      /* fixed-point value does not fit i64      fixed.rs:65-70         */
+    DCDF_ERR_BOUNDS = -5,        /* query outside the chunk                 mmarray.rs:218-229     */
+    DCDF_ERR_TOO_MANY_LOGS = -6, /* unreachable through build (254 cap)     block.rs:27-32         */
+    DCDF_ERR_FORMAT = -7,        /* malformed encoded chunk on open         chunk.rs:247-266       */
+    DCDF_ERR_UNSUPPORTED = -8,   /* k != 2, sidelen > 256, or |value| >= 2^30      */
+    DCDF_ERR_NO_DEVICE = -9,     /* no gfx950 device / HIP runtime failure                         */
+    DCDF_ERR_NOMEM = -10,
+    DCDF_ERR_CAPACITY = -11      /* result buffer too small (search): *n holds the needed count    */
+};
+
+/* One `Chunk::build` input: a borrowed strided 3-D view [instants, rows, cols]
+ * (mmbuffer.rs:255-260; tile slices are non-contiguous, mmbuffer.rs:517-522).
+ * Not mutated, no pointer retained after the call returns. */
+typedef struct dcdf_tile_desc {
+    const void* base;                      /* element [0,0,0]                                   */
+    int32_t dtype;                         /* DCDF_I32 / I64 / F32 / F64                         */
+    int32_t _pad0;
+    int64_t stride_t, stride_r, stride_c;  /* in ELEMENTS                                        */
+    uint32_t instants, rows, cols;
+    uint8_t fractional_bits;               /* floats only (mmbuffer.rs:554-571)                  */
+    uint8_t round;                         /* floats only: lossy rounding allowed (fixed.rs:46)  */
+    uint8_t _pad1[2];
+} dcdf_tile_desc;
+
+/* One `MMStruct3Build` (mmstruct.rs:24-34) for a Subchunk: serialized bytes + counters. */
+typedef struct dcdf_encoded {
+    uint8_t* bytes;       /* == Chunk::write_to image (chunk.rs:235-243); library-owned host memory   */
+    size_t len;           /* == Chunk::size()  (chunk.rs:272-277)                                      */
+    uint32_t snapshots;   /* chunk.rs:93-94                                                            */
+    uint32_t logs;
+    int32_t status;       /* per-tile DCDF_* code; bytes == NULL when != 0                             */
+    int32_t _pad;
+    int64_t* minmax;      /* [instants][2] stored-value (min,max) per instant = root of each k2 tree;  */
+                          /* what Superchunk::build recomputes at superchunk.rs:144 (mmbuffer.rs:366)  */
+} dcdf_encoded;
+
+/* ---- encode -------------------------------------------------------------------------------- */
+
+/* Replaces `Chunk::build(buffer, shape, k)` (chunk.rs:42-96) called per tile from
+ * superchunk.rs:169, for n independent tiles at once.  Returns 0 if the call itself ran
+ * (inspect out[i].status per tile) or a negative code for a whole-call failure.
+ * `mem` says where tiles[i].base lives.  *out is an array of n records; free with
+ * dcdf_free_encoded(*out, n). */
+int dcdf_chunk_build_batch(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dcdf_encoded** out);
+
+/* Single tile == batch of 1 (chunk.rs:42). */
+int dcdf_chunk_build(const dcdf_tile_desc* tile, int k, int mem, dcdf_encoded** out);
+
+void dcdf_free_encoded(dcdf_encoded* out, size_t n);
+
+/* Device-resident encode session (what bench.py times: inputs already in HBM, outputs stay in HBM).
+ * tiles[i].base must be device pointers.  `out_cap_per_tile` bytes of device output are reserved
+ * per tile (0 = library default = raw tile bytes + 4 KiB). */
+typedef struct dcdf_encoder dcdf_encoder;
+int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k, size_t out_cap_per_tile, dcdf_encoder** enc);
+/* Launches the encode kernels on the session's stream and waits.  kernel_ms (may be NULL) receives
+ * the HIP-event time of the encode kernel alone. */
+int dcdf_encoder_run(dcdf_encoder* enc, float* kernel_ms);
+/* Per-tile results of the last run (host copies of the small tables; bytes stay on the device). */
+int dcdf_encoder_result(dcdf_encoder* enc, size_t i, int32_t* status, uint64_t* len, uint32_t* snapshots,
+                        uint32_t* logs, const uint8_t** device_bytes);
+/* Copies tile i's encoded bytes to host memory `dst` (cap >= len). */
+int dcdf_encoder_fetch(dcdf_encoder* enc, size_t i, uint8_t* dst, size_t cap);
+/* Sum of len over tiles with status 0 (for the algorithmic-bytes figure). */
+uint64_t dcdf_encoder_total_bytes(dcdf_encoder* enc);
+void dcdf_encoder_destroy(dcdf_encoder* enc);
+
+/* ---- query --------------------------------------------------------------------------------- */
+
+typedef struct dcdf_chunk dcdf_chunk; /* an opened, device-resident encoded chunk */
+
+/* geom::Cube (geom.rs:71-103): half-open bounds; reversed bounds are swapped as in the reference. */
+typedef struct dcdf_cube {
+    uint32_t start, end, top, bottom, left, right;
+} dcdf_cube;
+
+/* Replaces `Chunk::read_from` (chunk.rs:247-266) + upload.  `bytes` is host memory. */
+int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h);
+void dcdf_chunk_close(dcdf_chunk* h);
+/* Chunk::shape (chunk.rs:119-123), encoding / fractional_bits (chunk.rs:33-38), block count. */
+int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* encoding, uint32_t* fractional_bits,
+                    uint32_t* n_blocks);
+
+/* Replaces `Chunk::get` (chunk.rs:127-131): stored i64 value (fixed-point for float chunks). */
+int dcdf_chunk_get(const dcdf_chunk* h, uint32_t instant, uint32_t row, uint32_t col, int64_t* out);
+/* Replaces `Chunk::fill_cell` (chunk.rs:135-148): out[end-start] stored i64 values (host). */
+int dcdf_chunk_fill_cell(const dcdf_chunk* h, uint32_t start, uint32_t end, uint32_t row, uint32_t col, int64_t* out);
+/* Replaces `Chunk::fill_window` (chunk.rs:152-158) with MMBuffer3::set conversion (mmbuffer.rs:292-299,
+ * 505,525,560,622): writes [end-start][bottom-top][right-left] into the caller's typed strided HOST array. */
+int dcdf_chunk_fill_window(const dcdf_chunk* h, const dcdf_cube* cube, void* out, int32_t out_dtype, int64_t stride_t,
+                           int64_t stride_r, int64_t stride_c);
+/* Replaces `Chunk::iter_search` (chunk.rs:213-229, 336-383): (instant,row,col) triples, sorted.
+ * cap = capacity of `out` in triples; *n = number found (DCDF_ERR_CAPACITY if > cap). */
+int dcdf_chunk_search(const dcdf_chunk* h, const dcdf_cube* cube, int64_t lower, int64_t upper, uint32_t* out,
+                      size_t cap, size_t* n);
+
+/* Batched queries against many opened chunks (BASELINE config 5).  All arrays are host memory.
+ * fill_window: query q writes its window, dense row-major i64 stored values, at out + out_offset[q]. */
+int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcdf_cube* cubes, size_t nq, int64_t* out,
+                                 const uint64_t* out_offset, float* kernel_ms);
+/* search: per-query counts in counts[q]; triples of query q at out + 3*offsets[q] (offsets = exclusive
+ * prefix of counts, written by the call); cap in triples. */
+int dcdf_query_search_batch(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const int64_t* lower,
+                            const int64_t* upper, size_t nq, uint32_t* out, size_t cap, uint64_t* counts,
+                            uint64_t* offsets, float* kernel_ms);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+/* fixed.rs:96-159 + mmbuffer.rs:596-613: per-tile suggest_fraction on the device; out_round = 1 for
+ * Fraction::Round.  Host or device data per `mem`. */
+int dcdf_suggest_fraction(const dcdf_tile_desc* tile, int mem, int32_t* out_round, int32_t* out_bits);
+
+/* Bench/test utility: fills dst[(t1-t0)][(r1-r0)][(c1-c0)] (DEVICE memory, dense) with the deterministic
+ * synthetic raster of SURVEY.md section 8(d) (same integers as dcdf_amd/synth.py; costab_host = its 1024-entry
+ * cosine table).  DCDF_I32 -> v, DCDF_I64 -> 2*v+1. */
+int dcdf_synth_fill(void* dst_device, int32_t dtype, uint64_t seed, int64_t t0, int64_t t1, int64_t r0, int64_t r1,
+                    int64_t c0, int64_t c1, const int32_t* costab_host);
+
+const char* dcdf_strerror(int code);
+/* "gfx950 <device name>, <CUs> CUs" or NULL when no device. */
+const char* dcdf_device_name(void);
+int dcdf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCDF_K2R_H */

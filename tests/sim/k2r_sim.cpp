@@ -1,0 +1,59 @@
+// k2r_sim.cpp -- TEST INFRASTRUCTURE ONLY.
+// Compiles the kernel bodies of dcdf_amd/csrc (the exact source hipcc builds for gfx950) with g++ and a
+// sequential execution context, so kernel logic can be checked on a GPU-less machine (and under
+// ASan/UBSan) before it runs on the card.  Not linked into libdcdf_k2r.so; the product cannot reach it.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../dcdf_amd/csrc/k2r_encode.h"
+
+using namespace k2r;
+
+template <int LOG2S, bool PADDED, bool VEC>
+static void run(const TileArgs& ta, TileResult* res) {
+    using C = EncCfg<LOG2S>;
+    auto sh = std::make_unique<EncShared<C>>();
+    std::memset(sh.get(), 0xA5, sizeof(*sh));  // poison: the kernel must initialise what it reads
+    SimExec<EncShared<C>, EncRegs, C::NT> ex(*sh);
+    std::vector<uint64_t> listV(C::MAXV + 1), listM(C::MAXT + 1);
+    encode_chunk<C, PADDED, VEC>(ex, ta, res, listV.data(), listM.data());
+}
+
+template <int LOG2S>
+static void run_l(const TileArgs& ta, TileResult* res, bool padded, bool vec) {
+    if (padded) run<LOG2S, true, false>(ta, res);
+    else if (vec) run<LOG2S, false, true>(ta, res);
+    else run<LOG2S, false, false>(ta, res);
+}
+
+extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, int64_t sc, uint32_t instants,
+                          uint32_t rows, uint32_t cols, int fbits, int round, uint8_t* out, uint64_t cap,
+                          int64_t* minmax, int force_novec, int32_t* status, uint32_t* snapshots, uint32_t* logs,
+                          uint64_t* len) {
+    TileArgs ta{};
+    ta.base = base; ta.st = st; ta.sr = sr; ta.sc = sc;
+    ta.instants = instants; ta.rows = rows; ta.cols = cols;
+    ta.dtype = dtype; ta.fbits = (dtype == ENC_F32 || dtype == ENC_F64) ? (uint32_t)fbits : 0; ta.round = (uint32_t)round;
+    ta.out = out; ta.out_cap = cap; ta.minmax = minmax;
+    uint32_t m = rows > cols ? rows : cols;
+    int lg = 0;
+    while ((1u << lg) < m) lg++;
+    if (lg < 3 || lg > 8 || instants == 0) return -8;
+    const uint32_t S = 1u << lg;
+    const bool padded = rows != S || cols != S;
+    const bool vec = !force_novec && !padded && dtype == ENC_I32 && sc == 1 && (sr % 4) == 0 && (st % 4) == 0 &&
+                     ((uintptr_t)base % 16) == 0;
+    TileResult res{};
+    switch (lg) {
+        case 3: run_l<3>(ta, &res, padded, vec); break;
+        case 4: run_l<4>(ta, &res, padded, vec); break;
+        case 5: run_l<5>(ta, &res, padded, vec); break;
+        case 6: run_l<6>(ta, &res, padded, vec); break;
+        case 7: run_l<7>(ta, &res, padded, vec); break;
+        case 8: run_l<8>(ta, &res, padded, vec); break;
+    }
+    *status = res.status; *snapshots = res.snapshots; *logs = res.logs; *len = res.len;
+    return 0;
+}

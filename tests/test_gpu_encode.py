@@ -1,0 +1,167 @@
+"""Parity tests proper: the HIP encoder, called through the C ABI, against the CPU oracle on the same
+seeded inputs, bit for bit.  Run on a real MI355X: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_vectors.json")) as f:
+    G = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def dc():
+    import dcdf_amd
+    from dcdf_amd import _lib
+    assert _lib.lib().dcdf_device_name(), "no GPU"
+    return dcdf_amd
+
+
+def farr(name, dtype):
+    return np.array([[[float("nan") if v == "nan" else v for v in row] for row in inst] for inst in G[name]], dtype=dtype)
+
+
+def array_n(n, T=12):
+    a8 = np.array(G["array8"], dtype=np.int64)
+    a = np.stack([a8[i % 3] for i in range(T)])
+    idx = np.arange(n) % 8
+    return np.ascontiguousarray(a[:, idx][:, :, idx])
+
+
+def assert_same(dc, arrays, **kw):
+    res = dc.build_batch(arrays, **kw)
+    okw = {"fractional_bits": kw.get("fractional_bits", 0), "round_": kw.get("round", False)}
+    for a, r in zip(arrays, res):
+        assert not isinstance(r, Exception), r
+        ref, rs, rl, _ = O.chunk_build(a, want_snapshots=True, **okw)
+        data = r.data.write_to()
+        assert (r.snapshots, r.logs) == (rs, rl)
+        if data != ref:
+            n = min(len(data), len(ref))
+            first = next((i for i in range(n) if data[i] != ref[i]), n)
+            raise AssertionError("bytes differ: len %d vs %d, first diff at %d, shape %s" % (len(data), len(ref), first, a.shape))
+        a3 = np.asarray(a)
+        fin = a3.reshape(a3.shape[0], -1)
+        if a3.dtype.kind == "i":
+            assert (r.minmax[:, 0] == fin.min(1)).all() and (r.minmax[:, 1] == fin.max(1)).all()
+        r.data.close()
+
+
+def test_reference_fixtures(dc):  # testing.rs:200-249 (array8 cycled / tiled), both int encodings
+    arrays = []
+    for n in (8, 16, 32, 64):
+        arrays += [array_n(n), array_n(n).astype(np.int32)]
+    arrays.append(np.array(G["array9"], dtype=np.int64))
+    pad = np.zeros((3, 9, 9), dtype=np.int64) + 5  # snapshot.rs:560-572, log.rs:939-955
+    pad[:, :8, :8] = np.array(G["array8"], dtype=np.int64)
+    pad[0] = np.array(G["array9"], dtype=np.int64)[0]
+    arrays.append(pad)
+    assert_same(dc, arrays)
+
+
+def test_random_kinds_all_sidelens(dc):
+    arrays = []
+    for shape in [(5, 8, 8), (7, 16, 16), (6, 32, 32), (5, 64, 64), (4, 128, 128), (3, 256, 256)]:
+        for kind in ["small", "wide", "noise", "const", "sparse"]:
+            rng = np.random.default_rng(hash((shape, kind)) & 0xFFFF)
+            T, R, Cc = shape
+            if kind == "small":
+                a = rng.integers(-3, 4, size=shape)
+            elif kind == "wide":
+                a = rng.integers(-(2 ** 29), 2 ** 29, size=shape)
+                a[1] = a[0] + rng.integers(-300, 300, size=(R, Cc))
+            elif kind == "noise":
+                a = rng.integers(0, 70000, size=shape)
+            elif kind == "const":
+                a = np.zeros(shape, dtype=np.int64) + 5
+                a[2:] += 1
+            else:
+                base = rng.integers(-100, 100, size=(R, Cc))
+                a = np.stack([base.copy() for _ in range(T)])
+                for i in range(1, T):
+                    for _ in range(3):
+                        a[i, rng.integers(R), rng.integers(Cc)] += rng.integers(-500, 500)
+                    if i == 3 % T:
+                        a[i, : R // 2, : Cc // 2] += 7
+            arrays += [a.astype(np.int64), a.astype(np.int32)]
+    assert_same(dc, arrays)
+
+
+def test_padded_and_ragged(dc):  # superchunk.rs:129-142 edge tiles; snapshot.rs:453-457 None cells
+    arrays = []
+    for rows, cols in [(5, 3), (8, 7), (9, 9), (16, 9), (17, 4), (13, 31), (33, 20), (64, 1), (100, 77), (129, 130),
+                       (7, 8), (200, 256), (256, 255)]:
+        rng = np.random.default_rng(rows * 1000 + cols)
+        a = rng.integers(-9, 9, size=(5, rows, cols)).astype(np.int64)
+        a[2] = a[1]
+        a[3] = a[1] + 4
+        a[4, : rows // 2] = a[1, : rows // 2]
+        b = rng.integers(-40000, 40000, size=(4, rows, cols)).astype(np.int32)
+        b[2, :, : max(1, cols // 2)] = b[0, :, : max(1, cols // 2)] - 3
+        arrays += [a, b]
+    assert_same(dc, arrays)
+
+
+def test_strided_views(dc):
+    from dcdf_amd import synth
+    big = synth.cells(7, 0, 4, 0, 96, 0, 160, np.int32)
+    tile = big[:, 32:96, 64:128]
+    assert_same(dc, [tile, tile[:, :, ::2][:, :32, :32], big.transpose(0, 2, 1)[:, :64, :64]])
+
+
+def test_float_chunks(dc):  # mmarray.rs:1285,1403; fixed.rs quirks
+    arrays32, arrays64 = [], []
+    for dtype, lst in ((np.float32, arrays32), (np.float64, arrays64)):
+        f8 = farr("farray8", dtype)
+        a = np.stack([f8[i % 6] for i in range(12)])
+        idx = np.arange(16) % 8
+        lst.append(np.ascontiguousarray(a[:, idx][:, :, idx]))
+    assert_same(dc, arrays32 + arrays64, fractional_bits=3)
+    assert_same(dc, arrays32 + arrays64, fractional_bits=2, round=True)
+    r = dc.build_batch(arrays32, fractional_bits=2, round=False)[0]
+    assert isinstance(r, Exception) and r.code == -3  # fixed.rs:47-59
+    b = arrays64[0].copy()
+    b[3, 2, 2] = -np.inf
+    r = dc.build_batch([b], fractional_bits=3)[0]
+    assert isinstance(r, Exception) and r.code == -2  # fixed.rs:39-41
+    neg = -np.abs(arrays64[0])  # negative non-integers: never rounded, never rejected (appendix A.15)
+    assert_same(dc, [neg], fractional_bits=1)
+
+
+def test_254_log_cap(dc):  # chunk.rs:62, block.rs:27
+    base = (np.add.outer(np.arange(8), np.arange(8)) % 5).astype(np.int64)
+    a = np.stack([base.copy() for _ in range(300)])
+    for i in range(1, 300):
+        a[i, i % 8, (i * 3) % 8] += 1
+    assert_same(dc, [a])
+
+
+def test_unsupported_inputs_are_reported(dc):
+    a = np.zeros((2, 8, 8), dtype=np.int64)
+    a[1, 3, 3] = 2 ** 30
+    r = dc.build_batch([a, np.zeros((2, 4, 4), dtype=np.int32), np.zeros((1, 300, 8), dtype=np.int32)])
+    assert all(isinstance(x, Exception) and x.code == -8 for x in r)
+    with pytest.raises(dc.DcdfError):
+        dc.Chunk.build(np.zeros((2, 8, 8), dtype=np.int32), k=3)
+
+
+def test_config2_sample_synthetic_256(dc):
+    """BASELINE config 2 shape ([32,256,256], seed 0xDCDF0002 + c), a few chunks, int32 and int64."""
+    from dcdf_amd import synth
+    arrays = [synth.cells(0xDCDF0002 + c, 0, 32, 0, 256, 0, 256, np.int32) for c in range(3)]
+    arrays.append(synth.cells(0xDCDF0002 + 3, 0, 32, 0, 256, 0, 256, np.int64))
+    arrays.append(synth.cells(0xDCDF0003, 352, 365, 1024, 1280, 2048, 2304, np.int32))  # ragged last segment (13)
+    assert_same(dc, arrays)
+
+
+def test_adversarial_sets(dc):  # iid noise (every instant a snapshot) and all-constant
+    rng = np.random.default_rng(9)
+    noise = rng.integers(0, 2 ** 30 - 1, size=(6, 256, 256)).astype(np.int32)
+    const = np.zeros((6, 256, 256), dtype=np.int32) + 1234
+    assert_same(dc, [noise, const])

@@ -1,0 +1,190 @@
+"""Query-path parity on the GPU: get / fill_cell / fill_window / search through the C ABI against the oracle
+(and against the raw arrays), modelled on chunk.rs:426-565, block.rs:201-304, snapshot.rs / log.rs sweeps."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_vectors.json")) as f:
+    G = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def dc():
+    import dcdf_amd
+    from dcdf_amd import _lib
+    assert _lib.lib().dcdf_device_name(), "no GPU"
+    return dcdf_amd
+
+
+def arr(name, dtype=np.int64):
+    return np.array([[[float("nan") if v == "nan" else v for v in row] for row in inst] for inst in G[name]], dtype=dtype)
+
+
+def array_n(n, T=100):
+    a8 = arr("array8")
+    a = np.stack([a8[i % 3] for i in range(T)])
+    idx = np.arange(n) % 8
+    return np.ascontiguousarray(a[:, idx][:, :, idx])
+
+
+def brute(a, s, e, t, b, l, r, lo, hi):
+    sub = a[s:e, t:b, l:r]
+    return set((int(i) + s, int(y) + t, int(x) + l) for i, y, x in zip(*np.nonzero((sub >= lo) & (sub <= hi))))
+
+
+def test_forced_blocks_exhaustive_8x8(dc):
+    """chunk.rs:397-565 helper layout (blocks of 4): every window, every [lower,upper] in 4..9, k = 2 and 3.
+    The encoded bytes come from the oracle (forced blocks / k=3 are not what Chunk::build emits)."""
+    a = np.stack([arr("array8")[i % 3] for i in range(8)])
+    for k in (2, 3):
+        data = O.chunk_build_forced(a, k=k, block_len=4)
+        c = dc.Chunk(data)
+        oc = O.Chunk(data)
+        assert c.shape() == [8, 8, 8]
+        for i in range(8):
+            for r in range(8):
+                for cc in range(8):
+                    assert c.get(i, r, cc) == a[i, r, cc]
+        for top in range(0, 8, 1):
+            for bottom in range(top + 1, 9, 2):
+                for left in range(0, 8, 1):
+                    for right in range(left + 1, 9, 3):
+                        w = c.fill_window(dc.Cube(0, 8, top, bottom, left, right))
+                        assert (w == a[:, top:bottom, left:right]).all()
+                        for lo, hi in [(4, 9), (5, 5), (6, 8), (3, 4), (9, 12)]:
+                            got = set(map(tuple, c.iter_search(dc.Cube(1, 7, top, bottom, left, right), lo, hi).tolist()))
+                            assert got == brute(a, 1, 7, top, bottom, left, right, lo, hi)
+                            assert got == set(map(tuple, oc.search(1, 7, top, bottom, left, right, lo, hi).tolist()))
+        c.close()
+
+
+def test_array9_padding_k2_k3(dc):  # snapshot.rs:602-625, log.rs:1039-1077
+    a = arr("array9")
+    for k in (2, 3):
+        data = O.chunk_build_forced(a, k=k, block_len=3)
+        c = dc.Chunk(data)
+        w = c.fill_window(dc.Cube(0, 3, 0, 9, 0, 9))
+        assert (w == a).all()
+        for lo in range(1, 11):
+            got = set(map(tuple, c.iter_search(dc.Cube(0, 3, 2, 9, 1, 9), lo, lo + 2).tolist()))
+            assert got == brute(a, 0, 3, 2, 9, 1, 9, lo, lo + 2)
+        c.close()
+
+
+def test_chunk_fixture_i64_built_on_gpu(dc):  # mmstruct.rs:452-459: Chunk::build([100,16,16])
+    a = array_n(16)
+    b = dc.Chunk.build(a)
+    c = b.data
+    assert b.snapshots + b.logs == 100 and c.shape() == [100, 16, 16]
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        i, r, cc = int(rng.integers(100)), int(rng.integers(16)), int(rng.integers(16))
+        assert c.get(i, r, cc) == a[i, r, cc]
+    for _ in range(20):
+        r, cc = int(rng.integers(16)), int(rng.integers(16))
+        s = int(rng.integers(100)); e = int(rng.integers(s, 101))
+        np.testing.assert_array_equal(c.fill_cell(s, e, r, cc), a[s:e, r, cc])
+    oc = O.Chunk(c.write_to())
+    for _ in range(40):
+        s = int(rng.integers(100)); e = int(rng.integers(s + 1, 101))
+        t = int(rng.integers(16)); bo = int(rng.integers(t + 1, 17))
+        l = int(rng.integers(16)); rr = int(rng.integers(l + 1, 17))
+        np.testing.assert_array_equal(c.fill_window(dc.Cube(s, e, t, bo, l, rr)), a[s:e, t:bo, l:rr])
+        lo = int(rng.integers(2, 10)); hi = int(rng.integers(lo, 10))
+        got = set(map(tuple, c.iter_search(dc.Cube(s, e, t, bo, l, rr), lo, hi).tolist()))
+        assert got == brute(a, s, e, t, bo, l, rr, lo, hi)
+        assert got == set(map(tuple, oc.search(s, e, t, bo, l, rr, lo, hi).tolist()))
+    # reversed bounds are swapped like geom::Cube::new / chunk.rs:214
+    got = c.iter_search(dc.Cube(5, 2, 9, 1, 12, 3), 7, 5)
+    assert set(map(tuple, got.tolist())) == brute(a, 2, 5, 1, 9, 3, 12, 5, 7)
+    res = got.tolist()
+    assert res == sorted(res)  # deterministic order: (instant,row,col) ascending
+    with pytest.raises(dc.DcdfError):
+        c.get(100, 0, 0)  # mmarray.rs:218-229 bounds panic -> DCDF_ERR_BOUNDS
+
+
+def test_typed_windows(dc):  # mmbuffer.rs:505,525,560,622 output conversions
+    a32 = array_n(16, T=10).astype(np.int32)
+    c = dc.Chunk.build(a32).data
+    assert c.encoding == 4
+    np.testing.assert_array_equal(c.fill_window(dc.Cube(0, 10, 0, 16, 0, 16)), a32)
+    out = np.zeros((10, 20, 24), dtype=np.int32)[:, 2:18, 4:20]  # strided caller buffer
+    c.fill_window(dc.Cube(0, 10, 0, 16, 0, 16), out=out)
+    np.testing.assert_array_equal(out, a32)
+    for dtype in (np.float32, np.float64):
+        f8 = arr("farray8", dtype)
+        a = np.stack([f8[i % 6] for i in range(12)])
+        idx = np.arange(16) % 8
+        a = np.ascontiguousarray(a[:, idx][:, :, idx])
+        c = dc.Chunk.build(a, fractional_bits=3).data
+        w = c.fill_window(dc.Cube(0, 12, 0, 16, 0, 16))
+        assert w.dtype == dtype
+        np.testing.assert_array_equal(np.isnan(w), np.isnan(a))
+        np.testing.assert_array_equal(w[~np.isnan(a)], a[~np.isnan(a)])
+        assert c.get(3, 0, 0) == 0 and c.get(0, 0, 0) == int(9.5 * 8) * 2 + 1  # NaN -> 0, finite -> odd
+
+
+def test_log_search_reference_quirk_reproduced(dc):
+    """Uniform single-node log over a multi-node snapshot: the reference's search descends as if eqB were 1
+    (see tests/test_oracle_roundtrip.py::test_log_search_uniform_log_reference_quirk).  Drop-in => same set."""
+    a8 = arr("array8")
+    for tv in (21, 5):
+        t = np.zeros((8, 8), dtype=np.int64) + tv
+        data = O.chunk_build_forced(np.stack([a8[0], t]), 2, 2)
+        c, oc = dc.Chunk(data), O.Chunk(data)
+        for lo in range(-2, 24):
+            for hi in range(lo, 24, 3):
+                got = set(map(tuple, c.iter_search(dc.Cube(1, 2, 1, 7, 2, 8), lo, hi).tolist()))
+                assert got == set(map(tuple, oc.search(1, 2, 1, 7, 2, 8, lo, hi).tolist()))
+
+
+def test_synthetic_256_roundtrip_and_batches(dc):
+    import ctypes as C
+    from dcdf_amd import synth, _lib as L
+    a = synth.cells(0xDCDF0001, 0, 16, 0, 256, 0, 256, np.int32)  # BASELINE config 1 shape
+    b = dc.Chunk.build(a)
+    c = b.data
+    np.testing.assert_array_equal(c.fill_window(dc.Cube(0, 16, 0, 256, 0, 256)), a)
+    rng = np.random.default_rng(1)
+    nq = 100
+    cubes = (L.Cube * nq)()
+    offs = np.zeros(nq, dtype=np.uint64)
+    total = 0
+    spec = []
+    for q in range(nq):
+        s = int(rng.integers(16)); e = min(16, s + int(rng.integers(1, 9)))
+        t = int(rng.integers(256)); bo = min(256, t + int(rng.integers(1, 65)))
+        l = int(rng.integers(256)); r = min(256, l + int(rng.integers(1, 65)))
+        cubes[q] = L.Cube(s, e, t, bo, l, r)
+        offs[q] = total
+        total += (e - s) * (bo - t) * (r - l)
+        spec.append((s, e, t, bo, l, r))
+    handles = (C.c_void_p * nq)(*[c._h for _ in range(nq)])
+    out = np.zeros(total, dtype=np.int64)
+    ms = C.c_float()
+    L.check(L.lib().dcdf_query_fill_window_batch(handles, cubes, C.c_size_t(nq), C.c_void_p(out.ctypes.data),
+                                                 C.c_void_p(offs.ctypes.data), C.byref(ms)))
+    for q, (s, e, t, bo, l, r) in enumerate(spec):
+        n = (e - s) * (bo - t) * (r - l)
+        np.testing.assert_array_equal(out[int(offs[q]):int(offs[q]) + n].reshape(e - s, bo - t, r - l), a[s:e, t:bo, l:r])
+    lo_v, hi_v = int(a.min()), int(a.max())
+    band = max(1, (hi_v - lo_v) // 10)
+    lower = np.array([lo_v + int(rng.integers(0, hi_v - lo_v - band)) for _ in range(nq)], dtype=np.int64)
+    upper = lower + band
+    counts = np.zeros(nq, dtype=np.uint64)
+    soffs = np.zeros(nq, dtype=np.uint64)
+    cap = total
+    res = np.zeros((cap, 3), dtype=np.uint32)
+    L.check(L.lib().dcdf_query_search_batch(handles, cubes, C.c_void_p(lower.ctypes.data), C.c_void_p(upper.ctypes.data),
+                                            C.c_size_t(nq), C.c_void_p(res.ctypes.data), C.c_size_t(cap),
+                                            C.c_void_p(counts.ctypes.data), C.c_void_p(soffs.ctypes.data), C.byref(ms)))
+    for q, (s, e, t, bo, l, r) in enumerate(spec):
+        got = set(map(tuple, res[int(soffs[q]):int(soffs[q] + counts[q])].tolist()))
+        assert got == brute(a, s, e, t, bo, l, r, int(lower[q]), int(upper[q]))

@@ -1,0 +1,151 @@
+"""Kernel-body logic (the source hipcc compiles for gfx950) run through the sequential host simulator and
+compared bit-for-bit with the oracle.  CPU-only pre-flight of the HIP path; the GPU tests repeat these
+comparisons through the C ABI on the card."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import sim_lib as S
+from dcdf_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_vectors.json")) as f:
+    G = json.load(f)
+
+
+def check(a, **kw):
+    okw = {k: v for k, v in kw.items() if k in ("fractional_bits", "round_")}
+    ref, rs, rl, _ = O.chunk_build(a, want_snapshots=True, **okw)
+    st, data, ns, nl, mm = S.encode(a, want_minmax=True, **kw)
+    assert st == 0
+    assert (ns, nl) == (rs, rl)
+    if data != ref:
+        n = min(len(data), len(ref))
+        first = next((i for i in range(n) if data[i] != ref[i]), n)
+        raise AssertionError("bytes differ: len %d vs %d, first diff at %d" % (len(data), len(ref), first))
+    return data, mm
+
+
+def array_n(n, T=12):
+    a8 = np.array(G["array8"], dtype=np.int64)
+    a = np.stack([a8[i % 3] for i in range(T)])
+    idx = np.arange(n) % 8
+    return a[:, idx][:, :, idx]
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64])
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_reference_fixture_tiled(n, dtype):  # testing.rs:242-249
+    check(array_n(n).astype(dtype))
+
+
+@pytest.mark.parametrize("shape", [(5, 8, 8), (7, 16, 16), (6, 32, 32), (5, 64, 64), (4, 128, 128)])
+@pytest.mark.parametrize("kind", ["small", "wide", "noise", "const", "sparse"])
+def test_random_unpadded(shape, kind):
+    rng = np.random.default_rng(hash((shape, kind)) & 0xFFFF)
+    T, R, Cc = shape
+    if kind == "small":
+        a = rng.integers(-3, 4, size=shape)
+    elif kind == "wide":  # forces 2-4 byte DAC values
+        a = rng.integers(-(2 ** 29), 2 ** 29, size=shape)
+        a[1] = a[0] + rng.integers(-300, 300, size=(R, Cc))
+    elif kind == "noise":
+        a = rng.integers(0, 70000, size=shape)
+    elif kind == "const":
+        a = np.zeros(shape, dtype=np.int64) + 5
+        a[2:] += 1
+    else:
+        base = rng.integers(-100, 100, size=(R, Cc))
+        a = np.stack([base.copy() for _ in range(T)])
+        for i in range(1, T):
+            for _ in range(3):
+                a[i, rng.integers(R), rng.integers(Cc)] += rng.integers(-500, 500)
+            if i == 3:
+                a[i, : R // 2, : Cc // 2] += 7  # "equal" quadrant (eqB = 1)
+    a = a.astype(np.int64)
+    check(a)
+    check(a.astype(np.int32))
+    check(a.astype(np.int32), force_novec=True)
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 3), (8, 7), (9, 9), (16, 9), (17, 4), (13, 31), (33, 20), (64, 1), (100, 77),
+                                       (129, 130), (7, 8)])
+def test_padded_shapes(rows, cols):
+    rng = np.random.default_rng(rows * 1000 + cols)
+    a = rng.integers(-9, 9, size=(5, rows, cols)).astype(np.int64)
+    a[2] = a[1]
+    a[3] = a[1] + 4
+    a[4, : rows // 2] = a[1, : rows // 2]
+    check(a)
+    b = rng.integers(-40000, 40000, size=(4, rows, cols)).astype(np.int32)
+    b[2, :, : max(1, cols // 2)] = b[0, :, : max(1, cols // 2)] - 3
+    check(b)
+
+
+def test_reference_padding_fixtures():  # snapshot.rs:560-572, log.rs:939-955
+    data = np.zeros((3, 9, 9), dtype=np.int64) + 5
+    data[:, :8, :8] = np.array(G["array8"], dtype=np.int64)
+    data[0] = np.array(G["array9"], dtype=np.int64)[0]
+    check(data)
+    check(np.array(G["array9"], dtype=np.int64))
+
+
+def test_synthetic_256():
+    a = synth.cells(0xDCDF0001, 0, 6, 0, 256, 0, 256, np.int32)
+    data, mm = check(a)
+    assert (mm[:, 0] == a.reshape(6, -1).min(1)).all() and (mm[:, 1] == a.reshape(6, -1).max(1)).all()
+    a64 = synth.cells(0xDCDF0001, 48, 52, 256, 512, 512, 768, np.int64)  # contains the repeated instant 49
+    check(a64)
+
+
+def test_non_contiguous_tile_view():
+    big = synth.cells(7, 0, 4, 0, 96, 0, 160, np.int32)
+    tile = big[:, 32:96, 64:128]
+    assert not tile.flags["C_CONTIGUOUS"]
+    check(tile)
+    check(tile[:, ::1, ::2][:, :32, :32])  # non-unit column stride
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_float_fixture(dtype):  # testing.rs:251-339, mmarray.rs:1285,1403
+    f8 = np.array([[[float("nan") if v == "nan" else v for v in row] for row in inst] for inst in G["farray8"]], dtype=dtype)
+    a = np.stack([f8[i % 6] for i in range(12)])
+    idx = np.arange(16) % 8
+    a = np.ascontiguousarray(a[:, idx][:, :, idx])
+    check(a, fractional_bits=3, round_=False)
+    check(a, fractional_bits=2, round_=True)  # lossy
+    st, data, _, _ = S.encode(a, fractional_bits=2, round_=False)
+    assert st == -3 and data is None  # precision loss (fixed.rs:47-59)
+    b = a.copy()
+    b[3, 2, 2] = np.inf
+    assert S.encode(b, fractional_bits=3)[0] == -2  # fixed.rs:39-41
+    with pytest.raises(O.OracleError):
+        O.chunk_build(b, fractional_bits=3)
+
+
+def test_254_log_cap():  # chunk.rs:62
+    base = (np.add.outer(np.arange(8), np.arange(8)) % 5).astype(np.int64)
+    a = np.stack([base.copy() for _ in range(300)])
+    for i in range(1, 300):
+        a[i, i % 8, (i * 3) % 8] += 1
+    check(a)
+
+
+def test_value_range_contract():
+    a = np.zeros((2, 8, 8), dtype=np.int64)
+    a[1, 3, 3] = 2 ** 30
+    assert S.encode(a)[0] == -8  # outside the fast path's |v| < 2^30 contract -> ST_UNSUPPORTED
+    a[1, 3, 3] = 2 ** 30 - 1
+    a[0, 0, 0] = -(2 ** 30)
+    check(a)
+
+
+def test_output_capacity_reported():
+    a = np.random.default_rng(0).integers(0, 1000, size=(3, 16, 16)).astype(np.int32)
+    ref = O.chunk_build(a)
+    assert S.encode(a, cap=len(ref) - 1)[0] == -100
+    st, data, _, _ = S.encode(a, cap=len(ref))
+    assert st == 0 and data == ref
