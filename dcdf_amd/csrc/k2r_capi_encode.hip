@@ -3,6 +3,7 @@
 // dcdf_encoder = a device-resident encode session: tile descriptors, per-tile output slots,
 // per-class work queues.  dcdf_chunk_build_batch = upload + session + fetch.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -211,6 +212,12 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
     int rc = run_classes(e, nullptr, kernel_ms);
     if (rc != DCDF_OK) return rc;
     K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++)
+        if (e->results[i].status == ST_INTERNAL) {
+            const uint32_t* d = e->results[i].dbg;
+            std::fprintf(stderr, "dcdf_k2r: internal guard tripped on tile %zu: count=%u code=%u instant=%u tid=%u value=%u limit=%u\n",
+                         i, d[0], d[1], d[2], d[3], d[4], d[5]);
+        }
     // Tiles whose slot was too small: re-encode them alone into worst-case slots (rare; not timed).
     std::vector<std::vector<uint32_t>> again(e->classes.size());
     bool any = false;
@@ -407,6 +414,7 @@ extern "C" const char* dcdf_strerror(int code) {
         case DCDF_ERR_NO_DEVICE: return "no usable gfx950 device / HIP failure";
         case DCDF_ERR_NOMEM: return "out of memory";
         case DCDF_ERR_CAPACITY: return "result buffer too small";
+        case DCDF_ERR_INTERNAL: return "internal consistency guard tripped in a kernel (bug; see stderr)";
     }
     return "unknown error";
 }

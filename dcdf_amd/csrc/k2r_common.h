@@ -31,6 +31,7 @@ enum : int32_t {
     ST_OVERFLOW = -4,
     ST_UNSUPPORTED = -8,
     ST_OUT_CAPACITY = -100,  // internal: output slot too small, host retries with a bigger slot
+    ST_INTERNAL = -101,      // an internal consistency guard tripped (bug); TileResult.dbg has the record
 };
 
 enum : int32_t { ENC_I32 = 4, ENC_I64 = 8, ENC_F32 = 32, ENC_F64 = 64 };
@@ -57,6 +58,8 @@ struct TileResult {
     uint32_t logs;
     uint32_t _pad;
     uint64_t len;
+    uint32_t dbg[6];  // guard record when status == ST_INTERNAL: count, code, instant, tid, value, limit
+    uint32_t _pad2[2];
 };
 
 K2R_HD uint32_t popc32(uint32_t x) { return (uint32_t)__builtin_popcount(x); }

@@ -61,6 +61,7 @@ struct EncShared {
     uint32_t nlistV, nlistM;
     int32_t err;
     uint32_t work;
+    uint32_t fault[6];  // [0] = count, [1..5] = first record (code, instant, tid, value, limit)
 };
 
 struct EncRegs {
@@ -314,6 +315,23 @@ struct Totals {
     }
 };
 
+// ---- internal consistency guard --------------------------------------------------------------------
+// Every computed stream position is checked against the count it must be below before it is used as an
+// address.  A violation can only come from a bug; it is recorded (first one wins) and the access skipped,
+// so a logic error surfaces as ST_INTERNAL with a diagnostic instead of an out-of-bounds access on the card.
+template <class EX>
+K2R_HD bool guard_ok(EX& ex, bool ok, uint32_t code, uint32_t inst, uint32_t tid, uint32_t value, uint32_t limit) {
+    if (ok) return true;
+    if (ex.lds_add(&ex.sh.fault[0], 1u) == 0) {
+        ex.sh.fault[1] = code;
+        ex.sh.fault[2] = inst;
+        ex.sh.fault[3] = tid;
+        ex.sh.fault[4] = value;
+        ex.sh.fault[5] = limit;
+    }
+    return false;
+}
+
 // ---- LDS bitmap helpers -------------------------------------------------------------------------
 // bit p lives in word p/32 at position 31-(p%32)  (bitmap.rs:176-183)
 template <class EX>
@@ -382,13 +400,19 @@ struct DacSink {
     uint32_t* bm0;     // LDS continuation bitmap of plane 0
     uint64_t* list;    // overflow entries (pos << 32 | remaining bytes)
     uint32_t* nlist;   // LDS counter
+    uint32_t n0;       // number of values of this Dac (positions are < n0)
+    uint32_t n1;       // number of values with more than one byte (list entries are < n1)
+    uint32_t inst;     // for diagnostics
+    uint32_t code;     // guard code base
 };
 template <class EX>
-K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz) {
+K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid) {
+    if (!guard_ok(ex, pos < d.n0, d.code, d.inst, (uint32_t)tid, pos, d.n0)) return;
     d.plane0[pos] = (uint8_t)zz;
     if (zz > 0xffu) {
         bm_set(ex, d.bm0, pos);
         const uint32_t slot = ex.lds_add(d.nlist, 1u);
+        if (!guard_ok(ex, slot < d.n1, d.code + 1, d.inst, (uint32_t)tid, slot, d.n1)) return;
         d.list[slot] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
     }
 }
@@ -416,7 +440,9 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
                 const uint32_t rem = (uint32_t)ent;
                 if (rem == 0) continue;  // value ended on an earlier plane
                 const uint32_t pos = (uint32_t)(ent >> 32);
+                if (!guard_ok(ex, pos < L.n[j], 40 + j, 0, (uint32_t)tid, pos, L.n[j])) continue;
                 const uint32_t q = bm_rank(cur, pref, pos);  // dac.rs:86
+                if (!guard_ok(ex, q < L.n[j + 1], 50 + j, 0, (uint32_t)tid, q, L.n[j + 1])) continue;
                 plane[q] = (uint8_t)rem;
                 const uint32_t rest = rem >> 8;
                 if (rest) bm_set(ex, nxt, q);
@@ -470,6 +496,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     ex.par([&](int tid, EncRegs&) {
         if (tid == 0) {
             sh.err = 0;
+            for (int i = 0; i < 6; i++) sh.fault[i] = 0;
             if (cap >= 6) {
                 out[0] = (uint8_t)ta.dtype;
                 out[1] = (uint8_t)ta.fbits;
@@ -784,8 +811,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
         });
 
-        const DacSink sinkV{io + DV.by_off[0], sh.bmV[0], listV, &sh.nlistV};
-        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM};
+        const DacSink sinkV{io + DV.by_off[0], sh.bmV[0], listV, &sh.nlistV, DV.n[0], DV.n[1], inst, 10};
+        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, 20};
 
         // 5b. plane 0 of both Dacs, T (and eqB) bits
         ex.par([&](int tid, EncRegs& r) {
@@ -807,14 +834,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 if (h < H) vrank = 4 * (unpackI(h + 1, pLo, pTop) - ((j & 3) ? 1u : 0u)) + (j & 3);
                 const uint32_t idx = TT.offV[h] + vrank;
                 const uint32_t irank = unpackI(h, pLo, pTop);
-                emit_val(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)));
+                emit_val(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
                 if (p) {
-                    bm_set(ex, sh.bmT, idx);
-                    emit_val(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)));
+                    if (guard_ok(ex, idx < TT.LT, 30, inst, (uint32_t)tid, idx, TT.LT)) bm_set(ex, sh.bmT, idx);
+                    emit_val(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
                 } else if (!as_snapshot) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
-                    if (e) bm_set(ex, sh.bmE, TT.offZ[h] + vrank - irank);
+                    if (e && guard_ok(ex, TT.offZ[h] + vrank - irank < TT.LT - TT.M0, 31, inst, (uint32_t)tid, TT.offZ[h] + vrank - irank, TT.LT - TT.M0))
+                        bm_set(ex, sh.bmE, TT.offZ[h] + vrank - irank);
                 }
             }
 
@@ -847,10 +875,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
                         const bool inv2 = inval(rj, cj);
                         const bool P2 = !inv2 && mn2[j] != mx2[j];
-                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? mx3 : mx3 - mx2[j]));
+                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? mx3 : mx3 - mx2[j]), tid);
                         tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
                         if (P2) {
-                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - mn3));
+                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - mn3), tid);
                             uint32_t tb1 = 0;
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
@@ -858,23 +886,23 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                                 const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
                                 const bool inv1 = inval(rq, cq);
                                 const bool P1 = !inv1 && mn1[q] != mx1[q];
-                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? mx2[j] : mx2[j] - mx1[q]));
+                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? mx2[j] : mx2[j] - mx1[q]), tid);
                                 tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
                                 if (P1) {
-                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - mn2[j]));
+                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - mn2[j]), tid);
 #pragma unroll
                                     for (int i = 0; i < 4; i++) {
                                         const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? mx1[q] : mx1[q] - r.t[4 * q + i]));
+                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? mx1[q] : mx1[q] - r.t[4 * q + i]), tid);
                                     }
                                     p0 += 4;
                                 }
                             }
-                            bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                            if (guard_ok(ex, p1 + 4 <= TT.LT, 32, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
                             p1 += 4;
                         }
                     }
-                    bm_or_run(ex, sh.bmT, p2, 4, tb2);
+                    if (guard_ok(ex, p2 + 4 <= TT.LT, 33, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
                 }
             } else {
                 // log: needs the snapshot's cells again (served from L2 / Infinity Cache)
@@ -887,7 +915,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 #pragma unroll
                     for (int m = 0; m < 16; m++) s64[16 * j + m] = s16[m];
                 }
-                int32_t smn1[16], smx1[16], smn2[4], smx2[4], df1[16], df2[4];
+                int32_t smn1[16], smx1[16], smn2[4], smx2[4], df1[16];
                 bool eq1[16], eq2[4];
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
@@ -909,7 +937,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     eq2[j] = eq1[4 * j] && eq1[4 * j + 1] && eq1[4 * j + 2] && eq1[4 * j + 3] &&
                              df1[4 * j] == df1[4 * j + 1] && df1[4 * j] == df1[4 * j + 2] &&
                              df1[4 * j] == df1[4 * j + 3];
-                    df2[j] = df1[4 * j];
+
                 }
                 const bool PL3 = !inv3 && mn3 != mx3 && sh.eq[tid] == 0;
                 if (PL3) {
@@ -923,13 +951,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         const bool inv2 = inval(rj, cj);
                         const bool unif2 = inv2 || mn2[j] == mx2[j];
                         const bool P2 = !unif2 && !eq2[j];
-                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? 0 : mx2[j] - smx2[j]));
+                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? 0 : mx2[j] - smx2[j]), tid);
                         tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
                         if (!P2) {
-                            if (!unif2) bm_set(ex, sh.bmE, z2);  // equal, log.rs:141-144
+                            if (!unif2 && guard_ok(ex, z2 < TT.LT - TT.M0, 34, inst, (uint32_t)tid, z2, TT.LT - TT.M0)) bm_set(ex, sh.bmE, z2);  // equal, log.rs:141-144
                             z2++;
                         } else {
-                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - smn2[j]));
+                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - smn2[j]), tid);
                             uint32_t tb1 = 0;
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
@@ -938,26 +966,26 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                                 const bool inv1 = inval(rq, cq);
                                 const bool unif1 = inv1 || mn1[q] == mx1[q];
                                 const bool P1 = !unif1 && !eq1[q];
-                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? 0 : mx1[q] - smx1[q]));
+                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? 0 : mx1[q] - smx1[q]), tid);
                                 tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
                                 if (!P1) {
-                                    if (!unif1) bm_set(ex, sh.bmE, z1);
+                                    if (!unif1 && guard_ok(ex, z1 < TT.LT - TT.M0, 35, inst, (uint32_t)tid, z1, TT.LT - TT.M0)) bm_set(ex, sh.bmE, z1);
                                     z1++;
                                 } else {
-                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - smn1[q]));
+                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - smn1[q]), tid);
 #pragma unroll
                                     for (int i = 0; i < 4; i++) {
                                         const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? 0 : r.t[4 * q + i] - s64[4 * q + i]));
+                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? 0 : r.t[4 * q + i] - s64[4 * q + i]), tid);
                                     }
                                     p0 += 4;
                                 }
                             }
-                            bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                            if (guard_ok(ex, p1 + 4 <= TT.LT, 32, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
                             p1 += 4;
                         }
                     }
-                    bm_or_run(ex, sh.bmT, p2, 4, tb2);
+                    if (guard_ok(ex, p2 + 4 <= TT.LT, 33, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
                 }
             }
         });
@@ -979,10 +1007,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 out[blk_hdr] = (uint8_t)blk_count;
                 store_be32(out + 2, n_blocks + 1);
             }
-            res->status = status;
+            const bool faulted = sh.fault[0] != 0;
+            res->status = faulted ? (int32_t)ST_INTERNAL : status;
             res->snapshots = n_snap;
             res->logs = n_log;
-            res->len = status == ST_OK ? off : 0;
+            res->len = (status == ST_OK && !faulted) ? off : 0;
+            for (int i = 0; i < 6; i++) res->dbg[i] = sh.fault[i];
         }
     });
 }

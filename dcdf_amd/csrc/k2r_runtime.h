@@ -51,6 +51,7 @@ inline int map_status(int32_t st) {
         case ST_OVERFLOW: return DCDF_ERR_OVERFLOW;
         case ST_UNSUPPORTED: return DCDF_ERR_UNSUPPORTED;
         case ST_BAD_ARG: return DCDF_ERR_BAD_ARG;
+        case ST_INTERNAL: return DCDF_ERR_INTERNAL;
         default: return DCDF_ERR_NO_DEVICE;
     }
 }

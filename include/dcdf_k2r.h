@@ -39,7 +39,8 @@ enum {
     DCDF_ERR_UNSUPPORTED = -8,   /* k != 2, sidelen > 256, or |value| >= 2^30      */
     DCDF_ERR_NO_DEVICE = -9,     /* no gfx950 device / HIP runtime failure                         */
     DCDF_ERR_NOMEM = -10,
-    DCDF_ERR_CAPACITY = -11      /* result buffer too small (search): *n holds the needed count    */
+    DCDF_ERR_CAPACITY = -11,     /* result buffer too small (search): *n holds the needed count    */
+    DCDF_ERR_INTERNAL = -12      /* an internal consistency guard of the kernels tripped (a bug)     */
 };
 
 /* One `Chunk::build` input: a borrowed strided 3-D view [instants, rows, cols]

@@ -17,6 +17,7 @@ static void run(const TileArgs& ta, TileResult* res) {
     auto sh = std::make_unique<EncShared<C>>();
     std::memset(sh.get(), 0xA5, sizeof(*sh));  // poison: the kernel must initialise what it reads
     SimExec<EncShared<C>, EncRegs, C::NT> ex(*sh);
+    std::memset((void*)ex.regs.data(), 0x5A, ex.regs.size() * sizeof(EncRegs));  // registers start as garbage on a GPU
     std::vector<uint64_t> listV(C::MAXV + 1), listM(C::MAXT + 1);
     encode_chunk<C, PADDED, VEC>(ex, ta, res, listV.data(), listM.data());
 }
