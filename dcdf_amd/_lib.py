@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcdf_k2r.so")
+LIB_PATH = os.environ.get("DCDF_K2R_LIB", os.path.join(_HERE, "libdcdf_k2r.so"))  # override: diagnostic builds
 
 DCDF_I32, DCDF_I64, DCDF_F32, DCDF_F64 = 4, 8, 32, 64
 MEM_HOST, MEM_DEVICE = 0, 1

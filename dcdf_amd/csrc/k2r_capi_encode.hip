@@ -212,6 +212,18 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
     int rc = run_classes(e, nullptr, kernel_ms);
     if (rc != DCDF_OK) return rc;
     K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
+    if (std::getenv("K2R_PROFILE_PRINT")) {
+        uint64_t acc[12] = {0};
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 12; k++) acc[k] += e->results[i].prof[k];
+        uint64_t tot = 0;
+        for (int k = 0; k < 12; k++) tot += acc[k];
+        static const char* names[12] = {"p1 load+analysis", "p2 top", "p3 own/top nodes", "scan8", "sizes+clear+hdr",
+                                        "emit snapshot", "emit log", "T/eqB bitmaps", "Lmax dac", "Lmin dac", "-", "-"};
+        for (int k = 0; k < 10; k++)
+            std::fprintf(stderr, "k2r-prof %-18s %14llu cyc %5.1f%%\n", names[k], (unsigned long long)acc[k],
+                         tot ? 100.0 * (double)acc[k] / (double)tot : 0.0);
+    }
     for (size_t i = 0; i < n; i++)
         if (e->results[i].status == ST_INTERNAL) {
             const uint32_t* d = e->results[i].dbg;

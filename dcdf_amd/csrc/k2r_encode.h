@@ -62,6 +62,7 @@ struct EncShared {
     int32_t err;
     uint32_t work;
     uint32_t fault[6];  // [0] = count, [1..5] = first record (code, instant, tid, value, limit)
+    uint64_t prof[12], prof_last;  // -DK2R_PROFILE only
 };
 
 struct EncRegs {
@@ -497,6 +498,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         if (tid == 0) {
             sh.err = 0;
             for (int i = 0; i < 6; i++) sh.fault[i] = 0;
+            for (int i = 0; i < 12; i++) sh.prof[i] = 0;
             if (cap >= 6) {
                 out[0] = (uint8_t)ta.dtype;
                 out[1] = (uint8_t)ta.fbits;
@@ -504,6 +506,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         }
     });
     if (cap < 7) status = ST_OUT_CAPACITY;
+#ifdef K2R_PROFILE
+    if (!EX::kSim) ex.par([&](int tid, EncRegs&) { if (tid == 0) sh.prof_last = clock64(); });
+#endif
 
     for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
         const bool have_s = inst > 0;
@@ -639,6 +644,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             status = sh.err == ERR_RANGE ? (int32_t)ST_UNSUPPORTED : sh.err;
             break;
         }
+        ex.stamp(0);  // phase 1: load + thread-local analysis
 
         // ================= phase 2: heights 4..H in LDS (snapshot.rs:476-497, log.rs:776-806) ==========
         for (int h = 4; h <= H; h++) {
@@ -663,6 +669,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             });
         }
 
+        ex.stamp(1);  // phase 2: top of the tree
         // node predicates on the top arrays (index = top_off(h) + j)
         auto PS = [&](int h, uint32_t j) -> bool {
             const int a = C::top_off(h) + (int)j;
@@ -730,7 +737,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[6] += lMax.pack18();
             r.sc[7] += lMin.pack16();
         });
+        ex.stamp(2);  // phase 3: own/top nodes
         ex.template scan<8>();
+        ex.stamp(3);  // the 8-field scan
 
         // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
         Totals<C> TS, TL;
@@ -811,6 +820,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
         });
 
+        ex.stamp(4);  // sizes, heuristic, clears, header
         const DacSink sinkV{io + DV.by_off[0], sh.bmV[0], listV, &sh.nlistV, DV.n[0], DV.n[1], inst, 10};
         const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, 20};
 
@@ -990,11 +1000,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
         });
 
+        ex.stamp(as_snapshot ? 5 : 6);  // plane-0 emission (5: snapshot, 6: log)
         // 5c. bitmaps + higher planes
         bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
         if (!as_snapshot) bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
+        ex.stamp(7);  // T / eqB bitmaps
         dac_finish<C>(ex, DV, io, sh.bmV[0], sh.bmV[1], sh.prefV, listV, &sh.nlistV);
+        ex.stamp(8);  // Lmax Dac: bitmaps + planes >= 1
         dac_finish<C>(ex, DM, io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
+        ex.stamp(9);  // Lmin Dac
 
         off += isize;
         blk_count++;
@@ -1013,6 +1027,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             res->logs = n_log;
             res->len = (status == ST_OK && !faulted) ? off : 0;
             for (int i = 0; i < 6; i++) res->dbg[i] = sh.fault[i];
+            for (int i = 0; i < 12; i++) res->prof[i] = sh.prof[i];
         }
     });
 }

@@ -38,6 +38,18 @@ struct GpuExec {
         f(tid, r);
     }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
+    // diagnostic builds only: attribute the cycles since the previous stamp to phase k (thread 0's view)
+    __device__ __forceinline__ void stamp(int k) {
+#ifdef K2R_PROFILE
+        if (tid == 0) {
+            const uint64_t t = clock64();
+            sh.prof[k] += t - sh.prof_last;
+            sh.prof_last = t;
+        }
+#else
+        (void)k;
+#endif
+    }
 
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
@@ -104,6 +116,7 @@ struct SimExec {
         for (int t = 0; t < NT; t++) f(t, regs[t]);
     }
     void barrier() {}
+    void stamp(int) {}
 
     uint32_t lds_or(uint32_t* p, uint32_t v) {
         uint32_t o = *p;
