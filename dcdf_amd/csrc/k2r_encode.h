@@ -66,7 +66,9 @@ struct EncShared {
 };
 
 struct EncRegs {
-    int32_t t[64];  // the current instant's cells of this thread's 8x8 block, Morton order
+    // summaries of the four height-2 nodes of this thread's 8x8 block, carried from analysis to emission
+    int32_t mn2[4], mx2[4], smn2[4], smx2[4];
+    uint32_t flags;  // bit j: eq2[j] (all cells of node j differ from the snapshot by one constant)
     uint64_t sc[MAX_SCAN_FIELDS];
     uint64_t pf_lo, pf_top;  // saved exclusive prefixes of the chosen candidate
 };
@@ -106,6 +108,15 @@ struct Cls {  // counts of values needing > 1, > 2, > 3 bytes
         c1 += (on && zz > 0xffu) ? 1u : 0u;
         c2 += (on && zz > 0xffffu) ? 1u : 0u;
         c3 += (on && zz > 0xffffffu) ? 1u : 0u;
+    }
+    // four values at once; the common case (all one byte) costs three ORs and a compare
+    K2R_HD void add4(uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3, bool on) {
+        if (on && ((z0 | z1 | z2 | z3) > 0xffu)) {
+            add(z0, true);
+            add(z1, true);
+            add(z2, true);
+            add(z3, true);
+        }
     }
     K2R_HD void add(const Cls& o, bool on) {
         c1 += on ? o.c1 : 0u;
@@ -259,6 +270,14 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
     }
 }
 
+// Keeps the instruction scheduler from hoisting the next sub-block's loads above the current sub-block's
+// arithmetic (which would keep 64+ extra cell registers live and spill under the 128-VGPR cap).
+K2R_HD void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // ---- sizes --------------------------------------------------------------
 struct DacLayout {
     uint32_t n[5];       // n[j] = # values with more than j bytes (n[0] = all); n[4] = 0
@@ -406,13 +425,23 @@ struct DacSink {
     uint32_t inst;     // for diagnostics
     uint32_t code;     // guard code base
 };
-template <class EX>
+// global-memory byte store (the pointers travel through structs, so the compiler would otherwise have to
+// emit flat_store_byte)
+K2R_HD void gstore8(uint8_t* p, uint8_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *(__attribute__((address_space(1))) uint8_t*)p = v;
+#else
+    *p = v;
+#endif
+}
+// WHICH = 0: Lmax Dac (sh.bmV[0], sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
+template <int WHICH, class EX>
 K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid) {
     if (!guard_ok(ex, pos < d.n0, d.code, d.inst, (uint32_t)tid, pos, d.n0)) return;
-    d.plane0[pos] = (uint8_t)zz;
+    gstore8(d.plane0 + pos, (uint8_t)zz);
     if (zz > 0xffu) {
-        bm_set(ex, d.bm0, pos);
-        const uint32_t slot = ex.lds_add(d.nlist, 1u);
+        bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV[0], pos);
+        const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
         if (!guard_ok(ex, slot < d.n1, d.code + 1, d.inst, (uint32_t)tid, slot, d.n1)) return;
         d.list[slot] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
     }
@@ -513,60 +542,108 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
         const bool have_s = inst > 0;
 
-        // ================= phase 1: load, thread-local pyramids, thread-local counts =================
+        // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
+        // Nothing but four per-height-2 summaries survives this phase in registers: cells are re-read on
+        // demand at emission, and only under visited subtrees (sparse for logs).
         ex.par([&](int tid, EncRegs& r) {
             uint32_t r0, c0;
             blk_origin(tid, r0, c0);
             int32_t err = 0;
-            load_block<PADDED, VEC>(ta, inst, r0, c0, r.t, err);
-
-            // ---- snapshot candidate (snapshot.rs:108-156) ----
-            int32_t mn1[16], mx1[16], mn2[4], mx2[4];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                mn1[q] = min4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
-                mx1[q] = max4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                mn2[j] = min4(mn1[4 * j], mn1[4 * j + 1], mn1[4 * j + 2], mn1[4 * j + 3]);
-                mx2[j] = max4(mx1[4 * j], mx1[4 * j + 1], mx1[4 * j + 2], mx1[4 * j + 3]);
-            }
-            const int32_t mn3 = min4(mn2[0], mn2[1], mn2[2], mn2[3]);
-            const int32_t mx3 = max4(mx2[0], mx2[1], mx2[2], mx2[3]);
             const bool inv3 = inval(r0, c0);
-            const bool P3 = !inv3 && mn3 != mx3;
-
-            uint32_t sI1 = 0, sI2 = 0;
-            Cls sMax, sMin;
-            // every in-thread difference is bounded by mx3-mn3: below 128 they all fit one byte
-            const bool need_cls = PADDED || (mx3 - mn3) >= 128;
+            uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0;
+            Cls sMax, sMin, lMax, lMin;
+            Cls lPend2;  // classes of the four height-2 log Lmax values, valid iff PL3 (known after the loop)
+            int32_t df2[4];
+            uint32_t eqbits = 0, eqall = 1;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                sched_fence();
                 const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
                 const bool inv2 = inval(rj, cj);
-                const bool P2 = !inv2 && mn2[j] != mx2[j];
-                sI2 += P2 ? 1u : 0u;
-                if (need_cls) {
-                    sMax.add(zz32(inv2 ? mx3 : mx3 - mx2[j]), P3);
-                    sMin.add(zz32(mn2[j] - mn3), P2);
-                }
+                int32_t t16[16];
+                load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, err);
+                int32_t mn1[4], mx1[4];
+                bool inv1[4], P1S[4];
 #pragma unroll
                 for (int qq = 0; qq < 4; qq++) {
-                    const int q = 4 * j + qq;
-                    const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                    const bool inv1 = inval(rq, cq);
-                    const bool P1 = !inv1 && mn1[q] != mx1[q];
-                    sI1 += P1 ? 1u : 0u;
-                    if (need_cls) {
-                        sMax.add(zz32(inv1 ? mx2[j] : mx2[j] - mx1[q]), P2);
-                        sMin.add(zz32(mn1[q] - mn2[j]), P1);
+                    mn1[qq] = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                    mx1[qq] = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                    inv1[qq] = inval(rj + 2 * (qq >> 1), cj + 2 * (qq & 1));
+                    P1S[qq] = !inv1[qq] && mn1[qq] != mx1[qq];
+                    sI1 += P1S[qq] ? 1u : 0u;
+                }
+                const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
+                const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
+                r.mn2[j] = mn2;
+                r.mx2[j] = mx2;
+                const bool P2S = !inv2 && mn2 != mx2;
+                sI2 += P2S ? 1u : 0u;
+                // ---- snapshot candidate (snapshot.rs:108-156): every difference inside node j is bounded by
+                //      mx2-mn2, below 128 they all take one byte and nothing needs classifying
+                if (PADDED || (mx2 - mn2) >= 128) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                        sMax.add(zz32(inv1[qq] ? mx2 : mx2 - mx1[qq]), P2S);
+                        sMin.add(zz32(mn1[qq] - mn2), P1S[qq]);
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                            sMax.add(zz32(inv0 ? mx1[q] : mx1[q] - r.t[4 * q + i]), P1);
+                            sMax.add(zz32(inv0 ? mx1[qq] : mx1[qq] - t16[4 * qq + i]), P1S[qq]);
                         }
                     }
+                }
+                // ---- log candidate vs. the open block's snapshot (log.rs:112-165, 725-817) ----
+                if (have_s) {
+                    int32_t s16[16];
+                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
+                    int32_t smn1[4], smx1[4], df1[4];
+                    bool eq1[4];
+                    Cls pend1;  // classes of the four height-1 Lmax values, valid iff P2L
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                        int32_t d[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
+                            d[i] = inv0 ? 0 : t16[4 * qq + i] - s16[4 * qq + i];  // log.rs:751
+                        }
+                        smn1[qq] = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                        smx1[qq] = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                        eq1[qq] = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];  // log.rs:780,805
+                        df1[qq] = d[0];
+                        const bool P1L = !inv1[qq] && mn1[qq] != mx1[qq] && !eq1[qq];  // log.rs:137-152
+                        lI1 += P1L ? 1u : 0u;
+                        lMax.add4(zz32(d[0]), zz32(d[1]), zz32(d[2]), zz32(d[3]), P1L);  // cells: t - s
+                        pend1.add(zz32(inv1[qq] ? 0 : mx1[qq] - smx1[qq]), true);         // log.rs:133
+                        lMin.add(zz32(mn1[qq] - smn1[qq]), P1L);                          // log.rs:148
+                    }
+                    const int32_t smn2 = min4(smn1[0], smn1[1], smn1[2], smn1[3]);
+                    const int32_t smx2 = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
+                    const bool eq2 = eq1[0] && eq1[1] && eq1[2] && eq1[3] && df1[0] == df1[1] && df1[0] == df1[2] &&
+                                     df1[0] == df1[3];
+                    df2[j] = df1[0];
+                    const bool P2L = !inv2 && mn2 != mx2 && !eq2;
+                    lI2 += P2L ? 1u : 0u;
+                    lMax.add(pend1, P2L);
+                    lPend2.add(zz32(inv2 ? 0 : mx2 - smx2), true);
+                    lMin.add(zz32(mn2 - smn2), P2L);
+                    r.smn2[j] = smn2;
+                    r.smx2[j] = smx2;
+                    eqbits |= (eq2 ? 1u : 0u) << j;
+                    eqall &= eq2 ? 1u : 0u;
+                }
+            }
+            const int32_t mn3 = min4(r.mn2[0], r.mn2[1], r.mn2[2], r.mn2[3]);
+            const int32_t mx3 = max4(r.mx2[0], r.mx2[1], r.mx2[2], r.mx2[3]);
+            const bool P3S = !inv3 && mn3 != mx3;
+            if (PADDED || (mx3 - mn3) >= 128) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
+                    sMax.add(zz32(inv2 ? mx3 : mx3 - r.mx2[j]), P3S);
+                    sMin.add(zz32(r.mn2[j] - mn3), !inv2 && r.mn2[j] != r.mx2[j]);
                 }
             }
             sh.tmin[tid] = mn3;
@@ -574,67 +651,18 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[0] = (uint64_t)sI1 | ((uint64_t)sI2 << 16);
             r.sc[2] = sMax.pack18();
             r.sc[3] = sMin.pack16();
-
-            // ---- log candidate vs. the open block's snapshot (log.rs:112-165, 725-817) ----
-            uint32_t lI1 = 0, lI2 = 0;
-            Cls lMax, lMin;
             if (have_s) {
-                int32_t smn2[4], smx2[4], df2[4];
-                bool eq2[4], P2v[4];
-                Cls pend2;  // classes of the height-2 Lmax values, valid iff P3 (known after the loop)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int32_t s16[16];
-                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
-                    const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-                    int32_t smn1[4], smx1[4], df1[4];
-                    bool eq1[4], P1v[4];
-                    Cls pend1;  // classes of the four height-1 Lmax values, valid iff P2
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq++) {
-                        const int q = 4 * j + qq;
-                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                        const bool inv1 = inval(rq, cq);
-                        int32_t d[4];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                            d[i] = inv0 ? 0 : r.t[4 * q + i] - s16[4 * qq + i];  // log.rs:751
-                        }
-                        smn1[qq] = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                        smx1[qq] = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                        eq1[qq] = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];  // log.rs:780,805
-                        df1[qq] = d[0];
-                        P1v[qq] = !inv1 && mn1[q] != mx1[q] && !eq1[qq];  // log.rs:137-152
-                        lI1 += P1v[qq] ? 1u : 0u;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) lMax.add(zz32(d[i]), P1v[qq]);   // cells: t - s
-                        pend1.add(zz32(inv1 ? 0 : mx1[q] - smx1[qq]), true);         // log.rs:133
-                        lMin.add(zz32(mn1[q] - smn1[qq]), P1v[qq]);                  // log.rs:148
-                    }
-                    const bool inv2 = inval(rj, cj);
-                    smn2[j] = min4(smn1[0], smn1[1], smn1[2], smn1[3]);
-                    smx2[j] = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
-                    eq2[j] = eq1[0] && eq1[1] && eq1[2] && eq1[3] && df1[0] == df1[1] && df1[0] == df1[2] &&
-                             df1[0] == df1[3];
-                    df2[j] = df1[0];
-                    P2v[j] = !inv2 && mn2[j] != mx2[j] && !eq2[j];
-                    lI2 += P2v[j] ? 1u : 0u;
-                    lMax.add(pend1, P2v[j]);
-                    pend2.add(zz32(inv2 ? 0 : mx2[j] - smx2[j]), true);
-                    lMin.add(zz32(mn2[j] - smn2[j]), P2v[j]);
-                }
-                const int32_t smn3 = min4(smn2[0], smn2[1], smn2[2], smn2[3]);
-                const int32_t smx3 = max4(smx2[0], smx2[1], smx2[2], smx2[3]);
-                const bool eq3 = eq2[0] && eq2[1] && eq2[2] && eq2[3] && df2[0] == df2[1] && df2[0] == df2[2] &&
-                                 df2[0] == df2[3];
+                const int32_t smn3 = min4(r.smn2[0], r.smn2[1], r.smn2[2], r.smn2[3]);
+                const int32_t smx3 = max4(r.smx2[0], r.smx2[1], r.smx2[2], r.smx2[3]);
+                const bool eq3 = eqall && df2[0] == df2[1] && df2[0] == df2[2] && df2[0] == df2[3];
                 const bool PL3 = !inv3 && mn3 != mx3 && !eq3;
-                lMax.add(pend2, PL3);
+                lMax.add(lPend2, PL3);
                 sh.smin[tid] = smn3;
                 sh.smax[tid] = smx3;
                 sh.diff[tid] = df2[0];
                 sh.eq[tid] = eq3 ? 1u : 0u;
             }
+            r.flags = eqbits;
             r.sc[4] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
             r.sc[6] = lMax.pack18();
             r.sc[7] = lMin.pack16();
@@ -844,10 +872,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 if (h < H) vrank = 4 * (unpackI(h + 1, pLo, pTop) - ((j & 3) ? 1u : 0u)) + (j & 3);
                 const uint32_t idx = TT.offV[h] + vrank;
                 const uint32_t irank = unpackI(h, pLo, pTop);
-                emit_val(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
+                emit_val<0>(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
                 if (p) {
                     if (guard_ok(ex, idx < TT.LT, 30, inst, (uint32_t)tid, idx, TT.LT)) bm_set(ex, sh.bmT, idx);
-                    emit_val(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
+                    emit_val<1>(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
                 } else if (!as_snapshot) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
@@ -856,54 +884,48 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 }
             }
 
-            // -- in-thread heights 2,1,0 --
-            int32_t mn1[16], mx1[16], mn2[4], mx2[4];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                mn1[q] = min4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
-                mx1[q] = max4(r.t[4 * q], r.t[4 * q + 1], r.t[4 * q + 2], r.t[4 * q + 3]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                mn2[j] = min4(mn1[4 * j], mn1[4 * j + 1], mn1[4 * j + 2], mn1[4 * j + 3]);
-                mx2[j] = max4(mx1[4 * j], mx1[4 * j + 1], mx1[4 * j + 2], mx1[4 * j + 3]);
-            }
+            // -- in-thread heights 2,1,0: cells are re-read per 4x4 sub-block, only under internal nodes --
             const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
             const bool inv3 = inval(r0, c0);
             const uint32_t E1 = unpackI(1, pLo, pTop), E2 = unpackI(2, pLo, pTop), E3 = unpackI(3, pLo, pTop);
+            int32_t lerr = 0;  // loads were validated in phase 1
 
             if (as_snapshot) {
                 const bool P3 = !inv3 && mn3 != mx3;
                 if (P3) {
-                    uint32_t p2 = TT.offV[2] + 4 * E3;  // my four height-2 nodes
-                    uint32_t p1 = TT.offV[1] + 4 * E2;  // running: my visited height-1 nodes
-                    uint32_t p0 = TT.offV[0] + 4 * E1;  // running: my visited cells
+                    const uint32_t p2 = TT.offV[2] + 4 * E3;  // my four height-2 nodes
+                    uint32_t p1 = TT.offV[1] + 4 * E2;        // running: my visited height-1 nodes
+                    uint32_t p0 = TT.offV[0] + 4 * E1;        // running: my visited cells
                     uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
                     uint32_t tb2 = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
                         const bool inv2 = inval(rj, cj);
-                        const bool P2 = !inv2 && mn2[j] != mx2[j];
-                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? mx3 : mx3 - mx2[j]), tid);
+                        const int32_t mn2 = r.mn2[j], mx2 = r.mx2[j];
+                        const bool P2 = !inv2 && mn2 != mx2;
+                        emit_val<0>(ex, sinkV, p2 + j, zz32(inv2 ? mx3 : mx3 - mx2), tid);
                         tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
                         if (P2) {
-                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - mn3), tid);
+                            emit_val<1>(ex, sinkM, i2++, zz32(mn2 - mn3), tid);
+                            int32_t t16[16];
+                            load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
                             uint32_t tb1 = 0;
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
-                                const int q = 4 * j + qq;
                                 const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
                                 const bool inv1 = inval(rq, cq);
-                                const bool P1 = !inv1 && mn1[q] != mx1[q];
-                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? mx2[j] : mx2[j] - mx1[q]), tid);
+                                const int32_t mn1 = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                                const int32_t mx1 = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                                const bool P1 = !inv1 && mn1 != mx1;
+                                emit_val<0>(ex, sinkV, p1 + qq, zz32(inv1 ? mx2 : mx2 - mx1), tid);
                                 tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
                                 if (P1) {
-                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - mn2[j]), tid);
+                                    emit_val<1>(ex, sinkM, i1++, zz32(mn1 - mn2), tid);
 #pragma unroll
                                     for (int i = 0; i < 4; i++) {
                                         const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? mx1[q] : mx1[q] - r.t[4 * q + i]), tid);
+                                        emit_val<0>(ex, sinkV, p0 + i, zz32(inv0 ? mx1 : mx1 - t16[4 * qq + i]), tid);
                                     }
                                     p0 += 4;
                                 }
@@ -915,79 +937,56 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     if (guard_ok(ex, p2 + 4 <= TT.LT, 33, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
                 }
             } else {
-                // log: needs the snapshot's cells again (served from L2 / Infinity Cache)
-                int32_t err = 0;
-                int32_t s64[64];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int32_t s16[16];
-                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
-#pragma unroll
-                    for (int m = 0; m < 16; m++) s64[16 * j + m] = s16[m];
-                }
-                int32_t smn1[16], smx1[16], smn2[4], smx2[4], df1[16];
-                bool eq1[16], eq2[4];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const uint32_t rq = r0 + 4 * ((q >> 2) >> 1) + 2 * ((q & 3) >> 1);
-                    const uint32_t cq = c0 + 4 * ((q >> 2) & 1) + 2 * ((q & 3) & 1);
-                    int32_t d[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : r.t[4 * q + i] - s64[4 * q + i];
-                    smn1[q] = min4(s64[4 * q], s64[4 * q + 1], s64[4 * q + 2], s64[4 * q + 3]);
-                    smx1[q] = max4(s64[4 * q], s64[4 * q + 1], s64[4 * q + 2], s64[4 * q + 3]);
-                    eq1[q] = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
-                    df1[q] = d[0];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    smn2[j] = min4(smn1[4 * j], smn1[4 * j + 1], smn1[4 * j + 2], smn1[4 * j + 3]);
-                    smx2[j] = max4(smx1[4 * j], smx1[4 * j + 1], smx1[4 * j + 2], smx1[4 * j + 3]);
-                    eq2[j] = eq1[4 * j] && eq1[4 * j + 1] && eq1[4 * j + 2] && eq1[4 * j + 3] &&
-                             df1[4 * j] == df1[4 * j + 1] && df1[4 * j] == df1[4 * j + 2] &&
-                             df1[4 * j] == df1[4 * j + 3];
-
-                }
                 const bool PL3 = !inv3 && mn3 != mx3 && sh.eq[tid] == 0;
                 if (PL3) {
-                    uint32_t p2 = TT.offV[2] + 4 * E3, p1 = TT.offV[1] + 4 * E2, p0 = TT.offV[0] + 4 * E1;
+                    const uint32_t p2 = TT.offV[2] + 4 * E3;
+                    uint32_t p1 = TT.offV[1] + 4 * E2, p0 = TT.offV[0] + 4 * E1;
                     uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
                     uint32_t z2 = TT.offZ[2] + 4 * E3 - E2, z1 = TT.offZ[1] + 4 * E2 - E1;
+                    const uint32_t ZL = TT.LT - TT.M0;
                     uint32_t tb2 = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
                         const bool inv2 = inval(rj, cj);
-                        const bool unif2 = inv2 || mn2[j] == mx2[j];
-                        const bool P2 = !unif2 && !eq2[j];
-                        emit_val(ex, sinkV, p2 + j, zz32(inv2 ? 0 : mx2[j] - smx2[j]), tid);
+                        const int32_t mn2 = r.mn2[j], mx2 = r.mx2[j];
+                        const bool unif2 = inv2 || mn2 == mx2;
+                        const bool P2 = !unif2 && ((r.flags >> j) & 1u) == 0;
+                        emit_val<0>(ex, sinkV, p2 + j, zz32(inv2 ? 0 : mx2 - r.smx2[j]), tid);
                         tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
                         if (!P2) {
-                            if (!unif2 && guard_ok(ex, z2 < TT.LT - TT.M0, 34, inst, (uint32_t)tid, z2, TT.LT - TT.M0)) bm_set(ex, sh.bmE, z2);  // equal, log.rs:141-144
+                            if (!unif2 && guard_ok(ex, z2 < ZL, 34, inst, (uint32_t)tid, z2, ZL)) bm_set(ex, sh.bmE, z2);  // log.rs:141-144
                             z2++;
                         } else {
-                            emit_val(ex, sinkM, i2++, zz32(mn2[j] - smn2[j]), tid);
+                            emit_val<1>(ex, sinkM, i2++, zz32(mn2 - r.smn2[j]), tid);
+                            int32_t t16[16], s16[16];
+                            load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
+                            load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);  // L2 / Infinity Cache hit
                             uint32_t tb1 = 0;
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
-                                const int q = 4 * j + qq;
                                 const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
                                 const bool inv1 = inval(rq, cq);
-                                const bool unif1 = inv1 || mn1[q] == mx1[q];
-                                const bool P1 = !unif1 && !eq1[q];
-                                emit_val(ex, sinkV, p1 + qq, zz32(inv1 ? 0 : mx1[q] - smx1[q]), tid);
+                                int32_t d[4];
+#pragma unroll
+                                for (int i = 0; i < 4; i++)
+                                    d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
+                                const int32_t mn1 = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                                const int32_t mx1 = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                                const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                                const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                                const bool eq1 = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
+                                const bool unif1 = inv1 || mn1 == mx1;
+                                const bool P1 = !unif1 && !eq1;
+                                emit_val<0>(ex, sinkV, p1 + qq, zz32(inv1 ? 0 : mx1 - smx1), tid);
                                 tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
                                 if (!P1) {
-                                    if (!unif1 && guard_ok(ex, z1 < TT.LT - TT.M0, 35, inst, (uint32_t)tid, z1, TT.LT - TT.M0)) bm_set(ex, sh.bmE, z1);
+                                    if (!unif1 && guard_ok(ex, z1 < ZL, 35, inst, (uint32_t)tid, z1, ZL)) bm_set(ex, sh.bmE, z1);
                                     z1++;
                                 } else {
-                                    emit_val(ex, sinkM, i1++, zz32(mn1[q] - smn1[q]), tid);
+                                    emit_val<1>(ex, sinkM, i1++, zz32(mn1 - smn1), tid);
 #pragma unroll
-                                    for (int i = 0; i < 4; i++) {
-                                        const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                                        emit_val(ex, sinkV, p0 + i, zz32(inv0 ? 0 : r.t[4 * q + i] - s64[4 * q + i]), tid);
-                                    }
+                                    for (int i = 0; i < 4; i++) emit_val<0>(ex, sinkV, p0 + i, zz32(d[i]), tid);
                                     p0 += 4;
                                 }
                             }
