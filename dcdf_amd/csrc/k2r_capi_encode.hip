@@ -86,8 +86,9 @@ static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls) {
     const uint32_t S = 1u << lg;
     cls->log2s = (int)lg;
     cls->padded = t.rows != S || t.cols != S;
-    cls->vec = !cls->padded && t.dtype == DCDF_I32 && t.stride_c == 1 && (t.stride_r % 4) == 0 &&
-               (t.stride_t % 4) == 0 && ((uintptr_t)t.base % 16) == 0;
+    cls->vec = !cls->padded && t.dtype == DCDF_I32 && t.stride_c == 1 && (t.stride_r % 4) == 0 && t.stride_r > 0 &&
+               (t.stride_t % 4) == 0 && ((uintptr_t)t.base % 16) == 0 &&
+               (uint64_t)(t.rows - 1) * (uint64_t)t.stride_r + t.cols < (1ull << 29);  // 32-bit byte offsets in the kernel
     return DCDF_OK;
 }
 
@@ -227,8 +228,8 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
     for (size_t i = 0; i < n; i++)
         if (e->results[i].status == ST_INTERNAL) {
             const uint32_t* d = e->results[i].dbg;
-            std::fprintf(stderr, "dcdf_k2r: internal guard tripped on tile %zu: count=%u code=%u instant=%u tid=%u value=%u limit=%u\n",
-                         i, d[0], d[1], d[2], d[3], d[4], d[5]);
+            std::fprintf(stderr, "dcdf_k2r: internal guard tripped on tile %zu: guard bitmask=0x%08x (bit = kGuard* in k2r_encode.h)\n",
+                         i, d[0]);
         }
     // Tiles whose slot was too small: re-encode them alone into worst-case slots (rare; not timed).
     std::vector<std::vector<uint32_t>> again(e->classes.size());

@@ -242,16 +242,20 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
                        int32_t& err) {
     const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
     if (VEC) {
-        const int32_t* p = (const int32_t*)ta.base + (int64_t)inst * ta.st + (int64_t)rj * ta.sr + cj;
+        // wave-uniform base of the instant (SGPR pair) + a 32-bit element offset per thread: the host only selects
+        // this path when (rows-1)*stride_r + cols < 2^31, so the offset arithmetic stays in 32 bits
+        const int32_t* ib = (const int32_t*)ta.base + (int64_t)inst * ta.st;
+        const uint32_t o0 = rj * (uint32_t)ta.sr + cj;
 #pragma unroll
         for (int dr = 0; dr < 4; dr++) {
-            const int32_t* q = p + (int64_t)dr * ta.sr;
+            const uint32_t o = o0 + (uint32_t)dr * (uint32_t)ta.sr;
             int32_t v[4];
 #if defined(__HIP_DEVICE_COMPILE__)
-            const int4 a = *(const int4*)q;
+            typedef __attribute__((address_space(1))) const char* gptr;
+            const int4 a = *(__attribute__((address_space(1))) const int4*)((gptr)ib + (uint64_t)o * 4u);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
 #else
-            for (int i = 0; i < 4; i++) v[i] = q[i];
+            for (int i = 0; i < 4; i++) v[i] = ib[o + i];
 #endif
 #pragma unroll
             for (int dc = 0; dc < 4; dc++) dst[cell_m(dr, dc)] = v[dc];
@@ -315,9 +319,11 @@ struct Totals {
     uint32_t LT, N0, M0;
     K2R_HD void from(uint64_t lo, uint64_t top) {
         constexpr int H = C::H;
+#pragma unroll
         for (int h = 1; h <= H; h++) Ni[h] = unpackI(h, lo, top);
         Ni[H + 1] = 0;
         uint32_t v = 0, i = 0, z = 0;
+#pragma unroll
         for (int h = H; h >= 0; h--) {
             uint32_t nv = (h == H) ? 1u : 4u * Ni[h + 1];
             offV[h] = v;
@@ -341,16 +347,16 @@ struct Totals {
 // so a logic error surfaces as ST_INTERNAL with a diagnostic instead of an out-of-bounds access on the card.
 template <class EX>
 K2R_HD bool guard_ok(EX& ex, bool ok, uint32_t code, uint32_t inst, uint32_t tid, uint32_t value, uint32_t limit) {
-    if (ok) return true;
-    if (ex.lds_add(&ex.sh.fault[0], 1u) == 0) {
-        ex.sh.fault[1] = code;
-        ex.sh.fault[2] = inst;
-        ex.sh.fault[3] = tid;
-        ex.sh.fault[4] = value;
-        ex.sh.fault[5] = limit;
-    }
+    if (__builtin_expect(ok, 1)) return true;
+    ex.lds_or(&ex.sh.fault[0], 1u << (code & 31u));  // cold path kept to one LDS atomic (codes: see kGuard*)
+    (void)inst; (void)tid; (void)value; (void)limit;
     return false;
 }
+// guard codes (bit numbers in TileResult.dbg[0])
+enum : uint32_t {
+    kGuardVPos = 0, kGuardVSlot = 1, kGuardMPos = 2, kGuardMSlot = 3, kGuardTOwn = 4, kGuardEOwn = 5, kGuardTRun1 = 6,
+    kGuardTRun2 = 7, kGuardE2 = 8, kGuardE1 = 9, kGuardListPos = 10, kGuardListRank = 14,
+};
 
 // ---- LDS bitmap helpers -------------------------------------------------------------------------
 // bit p lives in word p/32 at position 31-(p%32)  (bitmap.rs:176-183)
@@ -447,6 +453,34 @@ K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int ti
     }
 }
 
+// Four values at consecutive positions pos..pos+3 (the children of one internal node are always adjacent in
+// level order): one unaligned 4-byte store of the plane-0 bytes; values longer than a byte take the slow path.
+K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    *(__attribute__((address_space(1))) u32_unaligned*)p = v;
+#else
+    __builtin_memcpy(p, &v, 4);
+#endif
+}
+template <int WHICH, class EX>
+K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3, int tid) {
+    if (!guard_ok(ex, pos + 4 <= d.n0, d.code, d.inst, (uint32_t)tid, pos, d.n0)) return;
+    gstore32u(d.plane0 + pos, (z0 & 0xffu) | ((z1 & 0xffu) << 8) | ((z2 & 0xffu) << 16) | (z3 << 24));
+    if ((z0 | z1 | z2 | z3) > 0xffu) {
+        const uint32_t z[4] = {z0, z1, z2, z3};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (z[i] > 0xffu) {
+                bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV[0], pos + i);
+                const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
+                if (guard_ok(ex, slot < d.n1, d.code + 1, d.inst, (uint32_t)tid, slot, d.n1))
+                    d.list[slot] = ((uint64_t)(pos + i) << 32) | (uint64_t)(z[i] >> 8);
+            }
+        }
+    }
+}
+
 // Planes 1..nlev-1 of one Dac from its overflow list; also writes every level's BitMap.
 // bmA = continuation bitmap of plane 0 (already complete), bmB = scratch for the next plane.
 template <class C, class EX>
@@ -455,14 +489,16 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
     constexpr int NT = C::NT;
     uint32_t* cur = bmA;
     uint32_t* nxt = bmB;
-    for (uint32_t j = 0; j < L.nlev; j++) {
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        if (j >= L.nlev) break;
         bitmap_finish_write<C>(ex, cur, L.n[j], pref, inst_out + L.bm_off[j]);
         if (j + 1 >= L.nlev) break;
         const uint32_t Wn = (L.n[j + 1] + 31) / 32;
         ex.par([&](int tid, EncRegs&) {
             for (uint32_t w = (uint32_t)tid; w <= Wn; w += NT) nxt[w] = 0;
         });
-        const uint32_t nl = *nlist_p;
+        const uint32_t nl = ex.uni(*nlist_p);
         uint8_t* plane = inst_out + L.by_off[j + 1];
         ex.par([&](int tid, EncRegs&) {
             for (uint32_t e = (uint32_t)tid; e < nl; e += NT) {
@@ -470,9 +506,9 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
                 const uint32_t rem = (uint32_t)ent;
                 if (rem == 0) continue;  // value ended on an earlier plane
                 const uint32_t pos = (uint32_t)(ent >> 32);
-                if (!guard_ok(ex, pos < L.n[j], 40 + j, 0, (uint32_t)tid, pos, L.n[j])) continue;
+                if (!guard_ok(ex, pos < L.n[j], kGuardListPos + j, 0, (uint32_t)tid, pos, L.n[j])) continue;
                 const uint32_t q = bm_rank(cur, pref, pos);  // dac.rs:86
-                if (!guard_ok(ex, q < L.n[j + 1], 50 + j, 0, (uint32_t)tid, q, L.n[j + 1])) continue;
+                if (!guard_ok(ex, q < L.n[j + 1], kGuardListRank + j, 0, (uint32_t)tid, q, L.n[j + 1])) continue;
                 plane[q] = (uint8_t)rem;
                 const uint32_t rest = rem >> 8;
                 if (rest) bm_set(ex, nxt, q);
@@ -668,8 +704,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[7] = lMin.pack16();
             if (err != 0) ex.lds_min(&sh.err, err);
         });
-        if (sh.err != 0) {
-            status = sh.err == ERR_RANGE ? (int32_t)ST_UNSUPPORTED : sh.err;
+        const int32_t perr = ex.uni(sh.err);
+        if (perr != 0) {
+            status = perr == ERR_RANGE ? (int32_t)ST_UNSUPPORTED : perr;
             break;
         }
         ex.stamp(0);  // phase 1: load + thread-local analysis
@@ -733,6 +770,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         ex.par([&](int tid, EncRegs& r) {
             uint64_t sLo = r.sc[0], sTop = 0, lLo = r.sc[4], lTop = 0;
             Cls sMax, sMin, lMax, lMin;
+#pragma unroll
             for (int h = 3; h <= H; h++) {
                 const uint32_t span = 1u << (2 * (h - 3));  // threads under one node of height h
                 if (((uint32_t)tid & (span - 1)) != 0) break;
@@ -766,13 +804,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[7] += lMin.pack16();
         });
         ex.stamp(2);  // phase 3: own/top nodes
-        ex.template scan<8>();
-        ex.stamp(3);  // the 8-field scan
+        ex.template reduce<8>();
+        ex.stamp(3);  // totals of all 8 fields
 
         // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
         Totals<C> TS, TL;
-        TS.from(sh.tot[0], sh.tot[1]);
-        const uint64_t sx = sh.tot[2], sn = sh.tot[3];
+        TS.from(ex.uni(sh.tot[0]), ex.uni(sh.tot[1]));
+        const uint64_t sx = ex.uni(sh.tot[2]), sn = ex.uni(sh.tot[3]);
         const DacLayout SV = dac_layout(13 + bitmap_size(TS.LT), TS.N0, (uint32_t)(sx & 0x3ffff),
                                         (uint32_t)((sx >> 18) & 0x3ffff), (uint32_t)((sx >> 36) & 0x3ffff));
         const DacLayout SM = dac_layout(SV.end, TS.M0, (uint32_t)(sn & 0xffff), (uint32_t)((sn >> 16) & 0xffff),
@@ -781,8 +819,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         DacLayout LV = SV, LM = SM;
         uint32_t log_size = 0, log_eq_off = 0;
         if (have_s) {
-            TL.from(sh.tot[4], sh.tot[5]);
-            const uint64_t lx = sh.tot[6], ln = sh.tot[7];
+            TL.from(ex.uni(sh.tot[4]), ex.uni(sh.tot[5]));
+            const uint64_t lx = ex.uni(sh.tot[6]), ln = ex.uni(sh.tot[7]);
             log_eq_off = 13 + bitmap_size(TL.LT);
             LV = dac_layout(log_eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, (uint32_t)(lx & 0x3ffff),
                             (uint32_t)((lx >> 18) & 0x3ffff), (uint32_t)((lx >> 36) & 0x3ffff));
@@ -815,9 +853,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             break;
         }
         uint8_t* const io = out + off;  // first byte of this Snapshot / Log
-        const Totals<C>& TT = as_snapshot ? TS : TL;
-        const DacLayout& DV = as_snapshot ? SV : LV;
-        const DacLayout& DM = as_snapshot ? SM : LM;
+        const Totals<C> TT = as_snapshot ? TS : TL;
+        const DacLayout DV = as_snapshot ? SV : LV;
+        const DacLayout DM = as_snapshot ? SM : LM;
+        // exclusive prefixes of the winner's internal counts (positions)
+        ex.par_nosync([&](int, EncRegs& r) {
+            r.sc[0] = as_snapshot ? r.sc[0] : r.sc[4];
+            r.sc[1] = as_snapshot ? r.sc[1] : r.sc[5];
+        });
+        ex.template scan<2>();
 
         // ================= phase 5: emission of the winner ===============================================
         // 5a. clear bitmaps, save prefixes, header
@@ -829,8 +873,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
             for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV[0][w] = 0;
             for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
-            r.pf_lo = as_snapshot ? r.sc[0] : r.sc[4];
-            r.pf_top = as_snapshot ? r.sc[1] : r.sc[5];
+            r.pf_lo = r.sc[0];
+            r.pf_top = r.sc[1];
             if (tid == 0) {
                 sh.nlistV = 0;
                 sh.nlistM = 0;
@@ -849,8 +893,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         });
 
         ex.stamp(4);  // sizes, heuristic, clears, header
-        const DacSink sinkV{io + DV.by_off[0], sh.bmV[0], listV, &sh.nlistV, DV.n[0], DV.n[1], inst, 10};
-        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, 20};
+        const DacSink sinkV{io + DV.by_off[0], sh.bmV[0], listV, &sh.nlistV, DV.n[0], DV.n[1], inst, kGuardVPos};
+        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, kGuardMPos};
 
         // 5b. plane 0 of both Dacs, T (and eqB) bits
         ex.par([&](int tid, EncRegs& r) {
@@ -859,6 +903,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             const uint64_t pLo = r.pf_lo, pTop = r.pf_top;
 
             // -- top nodes owned by this thread, and its own height-3 node --
+#pragma unroll
             for (int h = 3; h <= H; h++) {
                 const uint32_t span = 1u << (2 * (h - 3));
                 if (((uint32_t)tid & (span - 1)) != 0) break;
@@ -874,12 +919,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 const uint32_t irank = unpackI(h, pLo, pTop);
                 emit_val<0>(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
                 if (p) {
-                    if (guard_ok(ex, idx < TT.LT, 30, inst, (uint32_t)tid, idx, TT.LT)) bm_set(ex, sh.bmT, idx);
+                    if (guard_ok(ex, idx < TT.LT, kGuardTOwn, inst, (uint32_t)tid, idx, TT.LT)) bm_set(ex, sh.bmT, idx);
                     emit_val<1>(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
                 } else if (!as_snapshot) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
-                    if (e && guard_ok(ex, TT.offZ[h] + vrank - irank < TT.LT - TT.M0, 31, inst, (uint32_t)tid, TT.offZ[h] + vrank - irank, TT.LT - TT.M0))
+                    if (e && guard_ok(ex, TT.offZ[h] + vrank - irank < TT.LT - TT.M0, kGuardEOwn, inst, (uint32_t)tid, TT.offZ[h] + vrank - irank, TT.LT - TT.M0))
                         bm_set(ex, sh.bmE, TT.offZ[h] + vrank - irank);
                 }
             }
@@ -897,44 +942,55 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     uint32_t p1 = TT.offV[1] + 4 * E2;        // running: my visited height-1 nodes
                     uint32_t p0 = TT.offV[0] + 4 * E1;        // running: my visited cells
                     uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
-                    uint32_t tb2 = 0;
+                    uint32_t tb2 = 0, z2v[4];
+                    bool P2[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
+                        const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
+                        P2[j] = !inv2 && r.mn2[j] != r.mx2[j];
+                        z2v[j] = zz32(inv2 ? mx3 : mx3 - r.mx2[j]);
+                        tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
+                    }
+                    emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
+                    if (guard_ok(ex, p2 + 4 <= TT.LT, kGuardTRun2, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (!P2[j]) continue;
                         const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-                        const bool inv2 = inval(rj, cj);
                         const int32_t mn2 = r.mn2[j], mx2 = r.mx2[j];
-                        const bool P2 = !inv2 && mn2 != mx2;
-                        emit_val<0>(ex, sinkV, p2 + j, zz32(inv2 ? mx3 : mx3 - mx2), tid);
-                        tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
-                        if (P2) {
-                            emit_val<1>(ex, sinkM, i2++, zz32(mn2 - mn3), tid);
-                            int32_t t16[16];
-                            load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
-                            uint32_t tb1 = 0;
+                        emit_val<1>(ex, sinkM, i2++, zz32(mn2 - mn3), tid);
+                        int32_t t16[16];
+                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
+                        uint32_t tb1 = 0, z1v[4];
+                        int32_t mn1[4], mx1[4];
+                        bool P1[4];
 #pragma unroll
-                            for (int qq = 0; qq < 4; qq++) {
-                                const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                                const bool inv1 = inval(rq, cq);
-                                const int32_t mn1 = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                                const int32_t mx1 = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                                const bool P1 = !inv1 && mn1 != mx1;
-                                emit_val<0>(ex, sinkV, p1 + qq, zz32(inv1 ? mx2 : mx2 - mx1), tid);
-                                tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
-                                if (P1) {
-                                    emit_val<1>(ex, sinkM, i1++, zz32(mn1 - mn2), tid);
+                        for (int qq = 0; qq < 4; qq++) {
+                            const bool inv1 = inval(rj + 2 * (qq >> 1), cj + 2 * (qq & 1));
+                            mn1[qq] = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                            mx1[qq] = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                            P1[qq] = !inv1 && mn1[qq] != mx1[qq];
+                            z1v[qq] = zz32(inv1 ? mx2 : mx2 - mx1[qq]);
+                            tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
+                        }
+                        emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
+                        if (guard_ok(ex, p1 + 4 <= TT.LT, kGuardTRun1, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                        p1 += 4;
 #pragma unroll
-                                    for (int i = 0; i < 4; i++) {
-                                        const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                                        emit_val<0>(ex, sinkV, p0 + i, zz32(inv0 ? mx1 : mx1 - t16[4 * qq + i]), tid);
-                                    }
-                                    p0 += 4;
-                                }
+                        for (int qq = 0; qq < 4; qq++) {
+                            if (!P1[qq]) continue;
+                            const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                            emit_val<1>(ex, sinkM, i1++, zz32(mn1[qq] - mn2), tid);
+                            uint32_t z0v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
+                                z0v[i] = zz32(inv0 ? mx1[qq] : mx1[qq] - t16[4 * qq + i]);
                             }
-                            if (guard_ok(ex, p1 + 4 <= TT.LT, 32, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
-                            p1 += 4;
+                            emit4<0>(ex, sinkV, p0, z0v[0], z0v[1], z0v[2], z0v[3], tid);
+                            p0 += 4;
                         }
                     }
-                    if (guard_ok(ex, p2 + 4 <= TT.LT, 33, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
                 }
             } else {
                 const bool PL3 = !inv3 && mn3 != mx3 && sh.eq[tid] == 0;
@@ -942,59 +998,71 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const uint32_t p2 = TT.offV[2] + 4 * E3;
                     uint32_t p1 = TT.offV[1] + 4 * E2, p0 = TT.offV[0] + 4 * E1;
                     uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
-                    uint32_t z2 = TT.offZ[2] + 4 * E3 - E2, z1 = TT.offZ[1] + 4 * E2 - E1;
+                    uint32_t zr2 = TT.offZ[2] + 4 * E3 - E2, zr1 = TT.offZ[1] + 4 * E2 - E1;
                     const uint32_t ZL = TT.LT - TT.M0;
-                    uint32_t tb2 = 0;
+                    uint32_t tb2 = 0, z2v[4];
+                    bool P2[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-                        const bool inv2 = inval(rj, cj);
-                        const int32_t mn2 = r.mn2[j], mx2 = r.mx2[j];
-                        const bool unif2 = inv2 || mn2 == mx2;
-                        const bool P2 = !unif2 && ((r.flags >> j) & 1u) == 0;
-                        emit_val<0>(ex, sinkV, p2 + j, zz32(inv2 ? 0 : mx2 - r.smx2[j]), tid);
-                        tb2 = (tb2 << 1) | (P2 ? 1u : 0u);
-                        if (!P2) {
-                            if (!unif2 && guard_ok(ex, z2 < ZL, 34, inst, (uint32_t)tid, z2, ZL)) bm_set(ex, sh.bmE, z2);  // log.rs:141-144
-                            z2++;
-                        } else {
-                            emit_val<1>(ex, sinkM, i2++, zz32(mn2 - r.smn2[j]), tid);
-                            int32_t t16[16], s16[16];
-                            load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
-                            load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);  // L2 / Infinity Cache hit
-                            uint32_t tb1 = 0;
-#pragma unroll
-                            for (int qq = 0; qq < 4; qq++) {
-                                const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                                const bool inv1 = inval(rq, cq);
-                                int32_t d[4];
-#pragma unroll
-                                for (int i = 0; i < 4; i++)
-                                    d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
-                                const int32_t mn1 = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                                const int32_t mx1 = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                                const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                                const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                                const bool eq1 = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
-                                const bool unif1 = inv1 || mn1 == mx1;
-                                const bool P1 = !unif1 && !eq1;
-                                emit_val<0>(ex, sinkV, p1 + qq, zz32(inv1 ? 0 : mx1 - smx1), tid);
-                                tb1 = (tb1 << 1) | (P1 ? 1u : 0u);
-                                if (!P1) {
-                                    if (!unif1 && guard_ok(ex, z1 < ZL, 35, inst, (uint32_t)tid, z1, ZL)) bm_set(ex, sh.bmE, z1);
-                                    z1++;
-                                } else {
-                                    emit_val<1>(ex, sinkM, i1++, zz32(mn1 - smn1), tid);
-#pragma unroll
-                                    for (int i = 0; i < 4; i++) emit_val<0>(ex, sinkV, p0 + i, zz32(d[i]), tid);
-                                    p0 += 4;
-                                }
-                            }
-                            if (guard_ok(ex, p1 + 4 <= TT.LT, 32, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
-                            p1 += 4;
+                        const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
+                        const bool unif2 = inv2 || r.mn2[j] == r.mx2[j];
+                        P2[j] = !unif2 && ((r.flags >> j) & 1u) == 0;
+                        z2v[j] = zz32(inv2 ? 0 : r.mx2[j] - r.smx2[j]);
+                        tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
+                        if (!P2[j]) {
+                            if (!unif2 && guard_ok(ex, zr2 < ZL, kGuardE2, inst, (uint32_t)tid, zr2, ZL)) bm_set(ex, sh.bmE, zr2);  // log.rs:141-144
+                            zr2++;
                         }
                     }
-                    if (guard_ok(ex, p2 + 4 <= TT.LT, 33, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
+                    emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
+                    if (guard_ok(ex, p2 + 4 <= TT.LT, kGuardTRun2, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (!P2[j]) continue;
+                        const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                        emit_val<1>(ex, sinkM, i2++, zz32(r.mn2[j] - r.smn2[j]), tid);
+                        int32_t t16[16], s16[16];
+                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
+                        load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);  // L2 / Infinity Cache hit
+                        uint32_t tb1 = 0, z1v[4], zmin[4];
+                        bool P1[4];
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                            const bool inv1 = inval(rq, cq);
+                            const int32_t mn1 = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                            const int32_t mx1 = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                            int32_t d[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
+                                t16[4 * qq + i] = d[i];  // from here on t16 holds t - s (what the cells emit)
+                            }
+                            const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                            const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                            const bool eq1 = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
+                            const bool unif1 = inv1 || mn1 == mx1;
+                            P1[qq] = !unif1 && !eq1;
+                            z1v[qq] = zz32(inv1 ? 0 : mx1 - smx1);
+                            zmin[qq] = zz32(mn1 - smn1);
+                            tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
+                            if (!P1[qq]) {
+                                if (!unif1 && guard_ok(ex, zr1 < ZL, kGuardE1, inst, (uint32_t)tid, zr1, ZL)) bm_set(ex, sh.bmE, zr1);
+                                zr1++;
+                            }
+                        }
+                        emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
+                        if (guard_ok(ex, p1 + 4 <= TT.LT, kGuardTRun1, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                        p1 += 4;
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            if (!P1[qq]) continue;
+                            emit_val<1>(ex, sinkM, i1++, zmin[qq], tid);
+                            emit4<0>(ex, sinkV, p0, zz32(t16[4 * qq]), zz32(t16[4 * qq + 1]), zz32(t16[4 * qq + 2]),
+                                     zz32(t16[4 * qq + 3]), tid);
+                            p0 += 4;
+                        }
+                    }
                 }
             }
         });

@@ -51,6 +51,32 @@ struct GpuExec {
 #endif
     }
 
+    // Values read from LDS are wave-uniform by construction here but the compiler cannot know: pin them into
+    // SGPRs so that the (large) amount of layout arithmetic derived from them stays off the vector registers.
+    __device__ __forceinline__ uint32_t uni(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    __device__ __forceinline__ int32_t uni(int32_t v) const { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ uint64_t uni(uint64_t v) const {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    }
+
+    // workgroup sum of r.sc[0..NF) -> sh.tot[0..NF) (no prefixes): wave butterfly + one LDS atomic per wave
+    template <int NF>
+    __device__ __forceinline__ void reduce() {
+        constexpr int W = NT < 64 ? NT : 64;
+        for (int f = tid; f < NF; f += NT) sh.tot[f] = 0;  // NT may be smaller than NF (sidelen 8, 16)
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            uint64_t v = r.sc[f];
+#pragma unroll
+            for (int d = W / 2; d >= 1; d >>= 1) v += __shfl_xor((unsigned long long)v, d, 64);
+            if ((tid & 63) == 0) atomicAdd((unsigned long long*)&sh.tot[f], (unsigned long long)v);
+        }
+        __syncthreads();
+    }
+
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
     __device__ __forceinline__ int32_t lds_min(int32_t* p, int32_t v) { return atomicMin(p, v); }
@@ -117,6 +143,16 @@ struct SimExec {
     }
     void barrier() {}
     void stamp(int) {}
+    template <class T>
+    T uni(T v) const { return v; }
+    template <int NF>
+    void reduce() {
+        for (int f = 0; f < NF; f++) {
+            uint64_t run = 0;
+            for (int t = 0; t < NT; t++) run += regs[t].sc[f];
+            sh.tot[f] = run;
+        }
+    }
 
     uint32_t lds_or(uint32_t* p, uint32_t v) {
         uint32_t o = *p;

@@ -44,8 +44,8 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
     if (lg < 3 || lg > 8 || instants == 0) return -8;
     const uint32_t S = 1u << lg;
     const bool padded = rows != S || cols != S;
-    const bool vec = !force_novec && !padded && dtype == ENC_I32 && sc == 1 && (sr % 4) == 0 && (st % 4) == 0 &&
-                     ((uintptr_t)base % 16) == 0;
+    const bool vec = !force_novec && !padded && dtype == ENC_I32 && sc == 1 && (sr % 4) == 0 && sr > 0 && (st % 4) == 0 &&
+                     ((uintptr_t)base % 16) == 0 && (uint64_t)(rows - 1) * (uint64_t)sr + cols < (1ull << 29);
     TileResult res{};
     switch (lg) {
         case 3: run_l<3>(ta, &res, padded, vec); break;
