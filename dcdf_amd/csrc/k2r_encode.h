@@ -347,10 +347,26 @@ struct Totals {
 // so a logic error surfaces as ST_INTERNAL with a diagnostic instead of an out-of-bounds access on the card.
 template <class EX>
 K2R_HD bool guard_ok(EX& ex, bool ok, uint32_t code, uint32_t inst, uint32_t tid, uint32_t value, uint32_t limit) {
-    if (__builtin_expect(ok, 1)) return true;
-    ex.lds_or(&ex.sh.fault[0], 1u << (code & 31u));  // cold path kept to one LDS atomic (codes: see kGuard*)
+    // branch-free on the hot path: the failure bit is OR-ed into a per-thread register (published to LDS once per
+    // phase by guard_flush) and the boolean predicates the guarded access
+    ex.gfail |= ok ? 0u : (1u << (code & 31u));
     (void)inst; (void)tid; (void)value; (void)limit;
-    return false;
+    return ok;
+}
+// position guard: returns pos when pos + span <= limit, else 0 (a safe in-range position: the tile is reported as
+// failed and its output discarded) -- no branch, no divergence
+template <class EX>
+K2R_HD uint32_t guard_pos(EX& ex, uint32_t pos, uint32_t span, uint32_t limit, uint32_t code) {
+    const bool ok = pos + span <= limit;
+    ex.gfail |= ok ? 0u : (1u << (code & 31u));
+    return ok ? pos : 0u;
+}
+template <class EX>
+K2R_HD void guard_flush(EX& ex) {
+    if (ex.gfail) {
+        ex.lds_or(&ex.sh.fault[0], ex.gfail);
+        ex.gfail = 0;
+    }
 }
 // guard codes (bit numbers in TileResult.dbg[0])
 enum : uint32_t {
@@ -443,13 +459,12 @@ K2R_HD void gstore8(uint8_t* p, uint8_t v) {
 // WHICH = 0: Lmax Dac (sh.bmV[0], sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
 template <int WHICH, class EX>
 K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid) {
-    if (!guard_ok(ex, pos < d.n0, d.code, d.inst, (uint32_t)tid, pos, d.n0)) return;
+    pos = guard_pos(ex, pos, 1, d.n0, d.code);
     gstore8(d.plane0 + pos, (uint8_t)zz);
     if (zz > 0xffu) {
         bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV[0], pos);
         const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
-        if (!guard_ok(ex, slot < d.n1, d.code + 1, d.inst, (uint32_t)tid, slot, d.n1)) return;
-        d.list[slot] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
+        d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
     }
 }
 
@@ -465,7 +480,7 @@ K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
 }
 template <int WHICH, class EX>
 K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3, int tid) {
-    if (!guard_ok(ex, pos + 4 <= d.n0, d.code, d.inst, (uint32_t)tid, pos, d.n0)) return;
+    pos = guard_pos(ex, pos, 4, d.n0, d.code);
     gstore32u(d.plane0 + pos, (z0 & 0xffu) | ((z1 & 0xffu) << 8) | ((z2 & 0xffu) << 16) | (z3 << 24));
     if ((z0 | z1 | z2 | z3) > 0xffu) {
         const uint32_t z[4] = {z0, z1, z2, z3};
@@ -474,8 +489,7 @@ K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t 
             if (z[i] > 0xffu) {
                 bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV[0], pos + i);
                 const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
-                if (guard_ok(ex, slot < d.n1, d.code + 1, d.inst, (uint32_t)tid, slot, d.n1))
-                    d.list[slot] = ((uint64_t)(pos + i) << 32) | (uint64_t)(z[i] >> 8);
+                d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)(pos + i) << 32) | (uint64_t)(z[i] >> 8);
             }
         }
     }
@@ -506,14 +520,14 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
                 const uint32_t rem = (uint32_t)ent;
                 if (rem == 0) continue;  // value ended on an earlier plane
                 const uint32_t pos = (uint32_t)(ent >> 32);
-                if (!guard_ok(ex, pos < L.n[j], kGuardListPos + j, 0, (uint32_t)tid, pos, L.n[j])) continue;
-                const uint32_t q = bm_rank(cur, pref, pos);  // dac.rs:86
-                if (!guard_ok(ex, q < L.n[j + 1], kGuardListRank + j, 0, (uint32_t)tid, q, L.n[j + 1])) continue;
+                const uint32_t posg = guard_pos(ex, pos, 1, L.n[j], kGuardListPos + j);
+                const uint32_t q = guard_pos(ex, bm_rank(cur, pref, posg), 1, L.n[j + 1], kGuardListRank + j);  // dac.rs:86
                 plane[q] = (uint8_t)rem;
                 const uint32_t rest = rem >> 8;
                 if (rest) bm_set(ex, nxt, q);
                 list[e] = ((uint64_t)q << 32) | (uint64_t)rest;
             }
+            guard_flush(ex);
         });
         uint32_t* t = cur;
         cur = nxt;
@@ -919,13 +933,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 const uint32_t irank = unpackI(h, pLo, pTop);
                 emit_val<0>(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
                 if (p) {
-                    if (guard_ok(ex, idx < TT.LT, kGuardTOwn, inst, (uint32_t)tid, idx, TT.LT)) bm_set(ex, sh.bmT, idx);
+                    bm_set(ex, sh.bmT, guard_pos(ex, idx, 1, TT.LT, kGuardTOwn));
                     emit_val<1>(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
                 } else if (!as_snapshot) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
-                    if (e && guard_ok(ex, TT.offZ[h] + vrank - irank < TT.LT - TT.M0, kGuardEOwn, inst, (uint32_t)tid, TT.offZ[h] + vrank - irank, TT.LT - TT.M0))
-                        bm_set(ex, sh.bmE, TT.offZ[h] + vrank - irank);
+                    if (e) bm_set(ex, sh.bmE, guard_pos(ex, TT.offZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
                 }
             }
 
@@ -952,7 +965,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
                     }
                     emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
-                    if (guard_ok(ex, p2 + 4 <= TT.LT, kGuardTRun2, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
+                    bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (!P2[j]) continue;
@@ -974,7 +987,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                             tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
                         }
                         emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
-                        if (guard_ok(ex, p1 + 4 <= TT.LT, kGuardTRun1, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                        bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
                         p1 += 4;
 #pragma unroll
                         for (int qq = 0; qq < 4; qq++) {
@@ -1010,12 +1023,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         z2v[j] = zz32(inv2 ? 0 : r.mx2[j] - r.smx2[j]);
                         tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
                         if (!P2[j]) {
-                            if (!unif2 && guard_ok(ex, zr2 < ZL, kGuardE2, inst, (uint32_t)tid, zr2, ZL)) bm_set(ex, sh.bmE, zr2);  // log.rs:141-144
+                            if (!unif2) bm_set(ex, sh.bmE, guard_pos(ex, zr2, 1, ZL, kGuardE2));  // log.rs:141-144
                             zr2++;
                         }
                     }
                     emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
-                    if (guard_ok(ex, p2 + 4 <= TT.LT, kGuardTRun2, inst, (uint32_t)tid, p2, TT.LT)) bm_or_run(ex, sh.bmT, p2, 4, tb2);
+                    bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (!P2[j]) continue;
@@ -1047,12 +1060,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                             zmin[qq] = zz32(mn1 - smn1);
                             tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
                             if (!P1[qq]) {
-                                if (!unif1 && guard_ok(ex, zr1 < ZL, kGuardE1, inst, (uint32_t)tid, zr1, ZL)) bm_set(ex, sh.bmE, zr1);
+                                if (!unif1) bm_set(ex, sh.bmE, guard_pos(ex, zr1, 1, ZL, kGuardE1));
                                 zr1++;
                             }
                         }
                         emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
-                        if (guard_ok(ex, p1 + 4 <= TT.LT, kGuardTRun1, inst, (uint32_t)tid, p1, TT.LT)) bm_or_run(ex, sh.bmT, p1, 4, tb1);
+                        bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
                         p1 += 4;
 #pragma unroll
                         for (int qq = 0; qq < 4; qq++) {
@@ -1065,6 +1078,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                 }
             }
+            guard_flush(ex);
         });
 
         ex.stamp(as_snapshot ? 5 : 6);  // plane-0 emission (5: snapshot, 6: log)

@@ -22,6 +22,7 @@ struct GpuExec {
     SH& sh;
     TR r;
     const int tid;
+    uint32_t gfail = 0;  // guard failure bits of this thread (k2r_encode.h guard_pos)
     static constexpr int kNT = NT;
     static constexpr bool kSim = false;
 
@@ -128,6 +129,7 @@ template <class SH, class TR, int NT>
 struct SimExec {
     SH& sh;
     std::vector<TR> regs;
+    uint32_t gfail = 0;
     static constexpr int kNT = NT;
     static constexpr bool kSim = true;
 
