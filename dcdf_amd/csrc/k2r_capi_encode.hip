@@ -220,8 +220,8 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
         uint64_t tot = 0;
         for (int k = 0; k < 12; k++) tot += acc[k];
         static const char* names[12] = {"p1 load+analysis", "p2 top", "p3 own/top nodes", "scan8", "sizes+clear+hdr",
-                                        "emit snapshot", "emit log", "T/eqB bitmaps", "Lmax dac", "Lmin dac", "-", "-"};
-        for (int k = 0; k < 10; k++)
+                                        "emit C snapshot", "emit C log", "T/eqB bitmaps", "Lmax dac", "Lmin dac", "emit pass A", "emit pass B"};
+        for (int k = 0; k < 12; k++)
             std::fprintf(stderr, "k2r-prof %-18s %14llu cyc %5.1f%%\n", names[k], (unsigned long long)acc[k],
                          tot ? 100.0 * (double)acc[k] / (double)tot : 0.0);
     }

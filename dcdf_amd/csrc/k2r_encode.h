@@ -37,7 +37,8 @@ struct EncCfg {
     static_assert(LOG2S >= 3 && LOG2S <= 8, "fast path covers sidelen 8..256");
     static constexpr int H = LOG2S;  // tree height; cells are height 0
     static constexpr int S = 1 << LOG2S;
-    static constexpr int NT = 1 << (2 * (LOG2S - 3));
+    static constexpr int NBLK = 1 << (2 * (LOG2S - 3));  // 8x8 blocks in the tile
+    static constexpr int NT = NBLK;                      // one thread per block
     static constexpr int NW = NT < 64 ? 1 : NT / 64;
     static constexpr int NTOP = ((1 << (2 * (H - 2))) - 1) / 3;  // nodes at heights 3..H
     static constexpr int MAXV = ((1 << (2 * (H + 1))) - 1) / 3;  // all nodes        (|Lmax|)
@@ -58,6 +59,10 @@ struct EncShared {
     uint32_t prefV[C::WV + 2], prefM[C::WT + 2];
     uint64_t wsum[C::NW][MAX_SCAN_FIELDS];
     uint64_t tot[MAX_SCAN_FIELDS];
+    // emission work lists, in level order: internal height-2 nodes (key = blk<<2|j, plus the number of internal
+    // quads before the item) and internal quads (key = blk<<4|j<<2|qq)
+    uint32_t L2[4 * C::NBLK];
+    uint16_t L1[16 * C::NBLK];
     uint32_t nlistV, nlistM;
     int32_t err;
     uint32_t work;
@@ -282,6 +287,39 @@ K2R_HD void sched_fence() {
 #endif
 }
 
+// the four cells of the 2x2 quad whose top-left cell is (rq,cq), row-major (== Morton) order
+template <bool PADDED, bool VEC>
+K2R_HD void load_quad(const TileArgs& ta, uint32_t inst, uint32_t rq, uint32_t cq, int32_t (&dst)[4], int32_t& err) {
+    if (VEC) {
+        const int32_t* ib = (const int32_t*)ta.base + (int64_t)inst * ta.st;
+        const uint32_t o0 = rq * (uint32_t)ta.sr + cq;
+#pragma unroll
+        for (int dr = 0; dr < 2; dr++) {
+            const uint32_t o = o0 + (uint32_t)dr * (uint32_t)ta.sr;
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef __attribute__((address_space(1))) const char* gptr;
+            const int2 a = *(__attribute__((address_space(1))) const int2*)((gptr)ib + (uint64_t)o * 4u);
+            dst[2 * dr] = a.x;
+            dst[2 * dr + 1] = a.y;
+#else
+            dst[2 * dr] = ib[o];
+            dst[2 * dr + 1] = ib[o + 1];
+#endif
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t r = rq + (i >> 1), c = cq + (i & 1);
+            if (PADDED) {
+                r = r < ta.rows ? r : ta.rows - 1;
+                c = c < ta.cols ? c : ta.cols - 1;
+            }
+            const int64_t off = (int64_t)inst * ta.st + (int64_t)r * ta.sr + (int64_t)c * ta.sc;
+            dst[i] = narrow(load_stored(ta, off, err), err);
+        }
+    }
+}
+
 // ---- sizes --------------------------------------------------------------
 struct DacLayout {
     uint32_t n[5];       // n[j] = # values with more than j bytes (n[0] = all); n[4] = 0
@@ -371,7 +409,7 @@ K2R_HD void guard_flush(EX& ex) {
 // guard codes (bit numbers in TileResult.dbg[0])
 enum : uint32_t {
     kGuardVPos = 0, kGuardVSlot = 1, kGuardMPos = 2, kGuardMSlot = 3, kGuardTOwn = 4, kGuardEOwn = 5, kGuardTRun1 = 6,
-    kGuardTRun2 = 7, kGuardE2 = 8, kGuardE1 = 9, kGuardListPos = 10, kGuardListRank = 14,
+    kGuardTRun2 = 7, kGuardE2 = 8, kGuardE1 = 9, kGuardListPos = 10, kGuardListRank = 14, kGuardList2 = 18, kGuardList1 = 19,
 };
 
 // ---- LDS bitmap helpers -------------------------------------------------------------------------
@@ -512,6 +550,7 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
         ex.par([&](int tid, EncRegs&) {
             for (uint32_t w = (uint32_t)tid; w <= Wn; w += NT) nxt[w] = 0;
         });
+        ex.barrier_global();  // the overflow list lives in global scratch and was appended to by other threads
         const uint32_t nl = ex.uni(*nlist_p);
         uint8_t* plane = inst_out + L.by_off[j + 1];
         ex.par([&](int tid, EncRegs&) {
@@ -604,7 +643,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             Cls sMax, sMin, lMax, lMin;
             Cls lPend2;  // classes of the four height-2 log Lmax values, valid iff PL3 (known after the loop)
             int32_t df2[4];
-            uint32_t eqbits = 0, eqall = 1;
+            uint32_t eqbits = 0, eqall = 1, cntbits = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 sched_fence();
@@ -621,6 +660,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     inv1[qq] = inval(rj + 2 * (qq >> 1), cj + 2 * (qq & 1));
                     P1S[qq] = !inv1[qq] && mn1[qq] != mx1[qq];
                     sI1 += P1S[qq] ? 1u : 0u;
+                    cntbits += (P1S[qq] ? 1u : 0u) << (4 + 3 * j);  // bits 4..15: internal quads per j, snapshot
                 }
                 const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
                 const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
@@ -665,6 +705,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         df1[qq] = d[0];
                         const bool P1L = !inv1[qq] && mn1[qq] != mx1[qq] && !eq1[qq];  // log.rs:137-152
                         lI1 += P1L ? 1u : 0u;
+                        cntbits += (P1L ? 1u : 0u) << (16 + 3 * j);  // bits 16..27: internal quads per j, log
                         lMax.add4(zz32(d[0]), zz32(d[1]), zz32(d[2]), zz32(d[3]), P1L);  // cells: t - s
                         pend1.add(zz32(inv1[qq] ? 0 : mx1[qq] - smx1[qq]), true);         // log.rs:133
                         lMin.add(zz32(mn1[qq] - smn1[qq]), P1L);                          // log.rs:148
@@ -712,7 +753,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.diff[tid] = df2[0];
                 sh.eq[tid] = eq3 ? 1u : 0u;
             }
-            r.flags = eqbits;
+            r.flags = eqbits | cntbits;
             r.sc[4] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
             r.sc[6] = lMax.pack18();
             r.sc[7] = lMin.pack16();
@@ -942,141 +983,150 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 }
             }
 
-            // -- in-thread heights 2,1,0: cells are re-read per 4x4 sub-block, only under internal nodes --
+            // -- the four height-2 children of this thread's block + the work list of internal height-2 nodes --
             const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
             const bool inv3 = inval(r0, c0);
             const uint32_t E1 = unpackI(1, pLo, pTop), E2 = unpackI(2, pLo, pTop), E3 = unpackI(3, pLo, pTop);
-            int32_t lerr = 0;  // loads were validated in phase 1
-
-            if (as_snapshot) {
-                const bool P3 = !inv3 && mn3 != mx3;
-                if (P3) {
-                    const uint32_t p2 = TT.offV[2] + 4 * E3;  // my four height-2 nodes
-                    uint32_t p1 = TT.offV[1] + 4 * E2;        // running: my visited height-1 nodes
-                    uint32_t p0 = TT.offV[0] + 4 * E1;        // running: my visited cells
-                    uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
-                    uint32_t tb2 = 0, z2v[4];
-                    bool P2[4];
+            const bool P3 = !inv3 && mn3 != mx3 && (as_snapshot || sh.eq[tid] == 0);
+            if (P3) {
+                const uint32_t p2 = TT.offV[2] + 4 * E3;
+                uint32_t tb2 = 0, z2v[4], zm2[4], erun = 0, elen = 0;
+                bool P2[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
-                        P2[j] = !inv2 && r.mn2[j] != r.mx2[j];
-                        z2v[j] = zz32(inv2 ? mx3 : mx3 - r.mx2[j]);
-                        tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
-                    }
-                    emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
-                    bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (!P2[j]) continue;
-                        const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-                        const int32_t mn2 = r.mn2[j], mx2 = r.mx2[j];
-                        emit_val<1>(ex, sinkM, i2++, zz32(mn2 - mn3), tid);
-                        int32_t t16[16];
-                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
-                        uint32_t tb1 = 0, z1v[4];
-                        int32_t mn1[4], mx1[4];
-                        bool P1[4];
-#pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            const bool inv1 = inval(rj + 2 * (qq >> 1), cj + 2 * (qq & 1));
-                            mn1[qq] = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                            mx1[qq] = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                            P1[qq] = !inv1 && mn1[qq] != mx1[qq];
-                            z1v[qq] = zz32(inv1 ? mx2 : mx2 - mx1[qq]);
-                            tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
-                        }
-                        emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
-                        bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
-                        p1 += 4;
-#pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            if (!P1[qq]) continue;
-                            const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                            emit_val<1>(ex, sinkM, i1++, zz32(mn1[qq] - mn2), tid);
-                            uint32_t z0v[4];
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                                z0v[i] = zz32(inv0 ? mx1[qq] : mx1[qq] - t16[4 * qq + i]);
-                            }
-                            emit4<0>(ex, sinkV, p0, z0v[0], z0v[1], z0v[2], z0v[3], tid);
-                            p0 += 4;
-                        }
-                    }
-                }
-            } else {
-                const bool PL3 = !inv3 && mn3 != mx3 && sh.eq[tid] == 0;
-                if (PL3) {
-                    const uint32_t p2 = TT.offV[2] + 4 * E3;
-                    uint32_t p1 = TT.offV[1] + 4 * E2, p0 = TT.offV[0] + 4 * E1;
-                    uint32_t i2 = TT.offI[2] + E2, i1 = TT.offI[1] + E1;
-                    uint32_t zr2 = TT.offZ[2] + 4 * E3 - E2, zr1 = TT.offZ[1] + 4 * E2 - E1;
-                    const uint32_t ZL = TT.LT - TT.M0;
-                    uint32_t tb2 = 0, z2v[4];
-                    bool P2[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
-                        const bool unif2 = inv2 || r.mn2[j] == r.mx2[j];
+                for (int j = 0; j < 4; j++) {
+                    const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
+                    const bool unif2 = inv2 || r.mn2[j] == r.mx2[j];
+                    if (as_snapshot) {
+                        P2[j] = !unif2;
+                        z2v[j] = zz32(inv2 ? mx3 : mx3 - r.mx2[j]);   // snapshot.rs:139
+                        zm2[j] = zz32(r.mn2[j] - mn3);                 // snapshot.rs:140
+                    } else {
                         P2[j] = !unif2 && ((r.flags >> j) & 1u) == 0;
-                        z2v[j] = zz32(inv2 ? 0 : r.mx2[j] - r.smx2[j]);
-                        tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
-                        if (!P2[j]) {
-                            if (!unif2) bm_set(ex, sh.bmE, guard_pos(ex, zr2, 1, ZL, kGuardE2));  // log.rs:141-144
-                            zr2++;
+                        z2v[j] = zz32(inv2 ? 0 : r.mx2[j] - r.smx2[j]);  // log.rs:133
+                        zm2[j] = zz32(r.mn2[j] - r.smn2[j]);             // log.rs:148
+                        if (!P2[j]) {  // T = 0: one eqB bit, set iff "equal" (log.rs:137-144)
+                            erun = (erun << 1) | (unif2 ? 0u : 1u);
+                            elen++;
                         }
                     }
-                    emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
-                    bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
+                    tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
+                }
+                emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
+                bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
+                if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
+                uint32_t n2 = 0, pre = E1;
+                const uint32_t cshift = as_snapshot ? 4u : 16u;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (!P2[j]) continue;
-                        const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-                        emit_val<1>(ex, sinkM, i2++, zz32(r.mn2[j] - r.smn2[j]), tid);
-                        int32_t t16[16], s16[16];
-                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
-                        load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);  // L2 / Infinity Cache hit
-                        uint32_t tb1 = 0, z1v[4], zmin[4];
-                        bool P1[4];
+                for (int j = 0; j < 4; j++) {
+                    if (P2[j]) {
+                        emit_val<1>(ex, sinkM, TT.offI[2] + E2 + n2, zm2[j], tid);
+                        sh.L2[guard_pos(ex, E2 + n2, 1, 4 * C::NBLK, kGuardList2)] = ((uint32_t)tid << 2) | (uint32_t)j | (pre << 12);
+                        n2++;
+                        pre += (r.flags >> (cshift + 3 * j)) & 7u;
+                    }
+                }
+            }
+            guard_flush(ex);
+        });
+
+        ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
+        // 5b'. one work item per internal height-2 node (dense, level order): its four height-1 children
+        const uint32_t nI2 = TT.Ni[2], nI1 = TT.Ni[1];
+        ex.par([&](int tid, EncRegs&) {
+            int32_t lerr = 0;  // loads were validated in phase 1
+            for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
+                const uint32_t ent = sh.L2[k];
+                const uint32_t blk = (ent >> 2) & (C::NBLK - 1), j = ent & 3u, pre = ent >> 12;
+                uint32_t r0, c0;
+                blk_origin((int)blk, r0, c0);
+                const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                int32_t t16[16];
+                load_sub16<PADDED, VEC>(ta, inst, r0, c0, (int)j, t16, lerr);
+                int32_t mn1[4], mx1[4];
+                bool inv1[4];
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                            const bool inv1 = inval(rq, cq);
-                            const int32_t mn1 = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                            const int32_t mx1 = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                            int32_t d[4];
+                for (int qq = 0; qq < 4; qq++) {
+                    mn1[qq] = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                    mx1[qq] = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                    inv1[qq] = inval(rj + 2 * (qq >> 1), cj + 2 * (qq & 1));
+                }
+                uint32_t z1v[4], zm1[4], tb1 = 0, erun = 0, elen = 0;
+                bool P1[4];
+                if (as_snapshot) {
+                    const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
+                    const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
 #pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
-                                t16[4 * qq + i] = d[i];  // from here on t16 holds t - s (what the cells emit)
-                            }
-                            const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                            const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                            const bool eq1 = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
-                            const bool unif1 = inv1 || mn1 == mx1;
-                            P1[qq] = !unif1 && !eq1;
-                            z1v[qq] = zz32(inv1 ? 0 : mx1 - smx1);
-                            zmin[qq] = zz32(mn1 - smn1);
-                            tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
-                            if (!P1[qq]) {
-                                if (!unif1) bm_set(ex, sh.bmE, guard_pos(ex, zr1, 1, ZL, kGuardE1));
-                                zr1++;
-                            }
-                        }
-                        emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
-                        bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
-                        p1 += 4;
+                    for (int qq = 0; qq < 4; qq++) {
+                        P1[qq] = !inv1[qq] && mn1[qq] != mx1[qq];
+                        z1v[qq] = zz32(inv1[qq] ? mx2 : mx2 - mx1[qq]);
+                        zm1[qq] = zz32(mn1[qq] - mn2);
+                        tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
+                    }
+                } else {
+                    int32_t s16[16];
+                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, (int)j, s16, lerr);  // L2 / Infinity Cache hit
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            if (!P1[qq]) continue;
-                            emit_val<1>(ex, sinkM, i1++, zmin[qq], tid);
-                            emit4<0>(ex, sinkV, p0, zz32(t16[4 * qq]), zz32(t16[4 * qq + 1]), zz32(t16[4 * qq + 2]),
-                                     zz32(t16[4 * qq + 3]), tid);
-                            p0 += 4;
+                    for (int qq = 0; qq < 4; qq++) {
+                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                        int32_t d[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
+                        const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                        const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                        const bool eq1 = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
+                        const bool unif1 = inv1[qq] || mn1[qq] == mx1[qq];
+                        P1[qq] = !unif1 && !eq1;
+                        z1v[qq] = zz32(inv1[qq] ? 0 : mx1[qq] - smx1);
+                        zm1[qq] = zz32(mn1[qq] - smn1);
+                        tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
+                        if (!P1[qq]) {
+                            erun = (erun << 1) | (unif1 ? 0u : 1u);
+                            elen++;
                         }
                     }
                 }
+                const uint32_t p1 = TT.offV[1] + 4 * k;  // level order: four children per internal parent
+                emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
+                bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
+                if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * k - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
+                uint32_t n1 = 0;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    if (P1[qq]) {
+                        emit_val<1>(ex, sinkM, TT.offI[1] + pre + n1, zm1[qq], tid);
+                        sh.L1[guard_pos(ex, pre + n1, 1, 16 * C::NBLK, kGuardList1)] = (uint16_t)((blk << 4) | (j << 2) | (uint32_t)qq);
+                        n1++;
+                    }
+                }
+            }
+            guard_flush(ex);
+        });
+
+        ex.stamp(11);  // emission pass B (height-1 groups)
+        // 5b''. one work item per internal quad: its four cells
+        ex.par([&](int tid, EncRegs&) {
+            int32_t lerr = 0;
+            for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
+                const uint32_t key = sh.L1[m];
+                const uint32_t blk = key >> 4, j = (key >> 2) & 3u, qq = key & 3u;
+                uint32_t r0, c0;
+                blk_origin((int)blk, r0, c0);
+                const uint32_t rq = r0 + 4 * (j >> 1) + 2 * (qq >> 1), cq = c0 + 4 * (j & 1) + 2 * (qq & 1);
+                int32_t t4[4];
+                load_quad<PADDED, VEC>(ta, inst, rq, cq, t4, lerr);
+                uint32_t z[4];
+                if (as_snapshot) {
+                    const int32_t mx1 = max4(t4[0], t4[1], t4[2], t4[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? mx1 : mx1 - t4[i]);
+                } else {
+                    int32_t s4[4];
+                    load_quad<PADDED, VEC>(ta, s_idx, rq, cq, s4, lerr);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t4[i] - s4[i]);
+                }
+                emit4<0>(ex, sinkV, TT.offV[0] + 4 * m, z[0], z[1], z[2], z[3], tid);
             }
             guard_flush(ex);
         });

@@ -28,17 +28,23 @@ struct GpuExec {
 
     __device__ GpuExec(SH& s) : sh(s), tid((int)threadIdx.x) {}
 
+    // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits (vmcnt(0)) for every global
+    // store of the wave to be acknowledged by L2 -- microseconds per phase here, for bytes nobody in the workgroup
+    // reads back.  Phases that DO hand global data to other threads use barrier_global().
+    __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    __device__ __forceinline__ void barrier_global() { __syncthreads(); }
+
     template <class F>
     __device__ __forceinline__ void par(F&& f) {
         f(tid, r);
-        __syncthreads();
+        lds_barrier();
     }
     // phase without trailing barrier (caller guarantees no hazard before the next barrier)
     template <class F>
     __device__ __forceinline__ void par_nosync(F&& f) {
         f(tid, r);
     }
-    __device__ __forceinline__ void barrier() { __syncthreads(); }
+    __device__ __forceinline__ void barrier() { lds_barrier(); }
     // diagnostic builds only: attribute the cycles since the previous stamp to phase k (thread 0's view)
     __device__ __forceinline__ void stamp(int k) {
 #ifdef K2R_PROFILE
@@ -67,7 +73,7 @@ struct GpuExec {
     __device__ __forceinline__ void reduce() {
         constexpr int W = NT < 64 ? NT : 64;
         for (int f = tid; f < NF; f += NT) sh.tot[f] = 0;  // NT may be smaller than NF (sidelen 8, 16)
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             uint64_t v = r.sc[f];
@@ -75,7 +81,7 @@ struct GpuExec {
             for (int d = W / 2; d >= 1; d >>= 1) v += __shfl_xor((unsigned long long)v, d, 64);
             if ((tid & 63) == 0) atomicAdd((unsigned long long*)&sh.tot[f], (unsigned long long)v);
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
@@ -101,7 +107,7 @@ struct GpuExec {
             incl[f] = v;
             if (lane == W - 1) sh.wsum[wave][f] = v;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             uint64_t base = 0, tot = 0;
@@ -114,7 +120,7 @@ struct GpuExec {
             r.sc[f] = base + incl[f] - r.sc[f];
             if (tid == 0) sh.tot[f] = tot;
         }
-        __syncthreads();
+        lds_barrier();
     }
 };
 
@@ -144,6 +150,7 @@ struct SimExec {
         for (int t = 0; t < NT; t++) f(t, regs[t]);
     }
     void barrier() {}
+    void barrier_global() {}
     void stamp(int) {}
     template <class T>
     T uni(T v) const { return v; }
