@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--dtype", choices=["i32", "i64"], default="i32")
     ap.add_argument("--cpu-sample", type=int, default=24, help="chunks timed on the CPU oracle (0 = skip)")
     ap.add_argument("--verify", type=int, default=4, help="chunks compared byte-for-byte with the oracle (untimed)")
+    ap.add_argument("--pad-elems", type=int, default=0, help="extra elements between consecutive chunks in HBM")
     args = ap.parse_args()
 
     import numpy as np
@@ -66,7 +67,9 @@ def main():
     tdt = torch.int32 if args.dtype == "i32" else torch.int64
     code = L.DCDF_I32 if args.dtype == "i32" else L.DCDF_I64
     esz = 4 if args.dtype == "i32" else 8
-    data = torch.empty((n, T, S, S), dtype=tdt, device="cuda")
+    per = T * S * S + args.pad_elems
+    flat = torch.empty((n * per,), dtype=tdt, device="cuda")
+    data = [flat[c * per:c * per + T * S * S].view(T, S, S) for c in range(n)]
     base_seed = 0xDCDF0002 + rank * n
     for c in range(n):
         synth_fill(data[c].data_ptr(), code, base_seed + c, 0, T, 0, S, 0, S)
@@ -113,7 +116,7 @@ def main():
             verified += 1
         if world == 1 and args.cpu_sample > 0:
             m = min(args.cpu_sample, n)
-            sample = data[:m].cpu().numpy()
+            sample = torch.stack(data[:m]).cpu().numpy()
             sec, tb, _ = O.bench_build(sample)
             cpu = {"value": m * T * S * S / sec, "unit": "cells/s", "cores": 1, "kind": "port",
                    "sample": "first %d of the %d [%d,%d,%d] %s chunks (%.1f s); C++ restatement of the Rust "

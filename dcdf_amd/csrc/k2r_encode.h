@@ -123,6 +123,8 @@ struct Cls {  // counts of values needing > 1, > 2, > 3 bytes
             add(z3, true);
         }
     }
+    // only the "> 1 byte" class, straight from the signed value: zig-zag(v) > 0xff  <=>  v < -128 || v > 127
+    K2R_HD void add1(int32_t v, bool on) { c1 += (on && ((uint32_t)v + 128u) > 255u) ? 1u : 0u; }
     K2R_HD void add(const Cls& o, bool on) {
         c1 += on ? o.c1 : 0u;
         c2 += on ? o.c2 : 0u;
@@ -141,6 +143,9 @@ constexpr int cell_m(int dr, int dc) {
 // Morton index m (0..63) -> (dr,dc)
 constexpr int m_dr(int m) { return (((m >> 5) & 1) << 2) | (((m >> 3) & 1) << 1) | ((m >> 1) & 1); }
 constexpr int m_dc(int m) { return (((m >> 4) & 1) << 2) | (((m >> 2) & 1) << 1) | (m & 1); }
+
+// 4-entry register array read with a runtime index (select chain; keeps rolled loops off scratch memory)
+K2R_HD int32_t sel4(const int32_t (&a)[4], int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
 
 K2R_HD int32_t min4(int32_t a, int32_t b, int32_t c, int32_t d) {
     int32_t x = a < b ? a : b, y = c < d ? c : d;
@@ -640,10 +645,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             int32_t err = 0;
             const bool inv3 = inval(r0, c0);
             uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0;
-            Cls sMax, sMin, lMax, lMin;
-            Cls lPend2;  // classes of the four height-2 log Lmax values, valid iff PL3 (known after the loop)
+            Cls lMax, lMin;
+            Cls lPend2;  // "> 1 byte" counts of the four height-2 log Lmax values, valid iff PL3
             int32_t df2[4];
-            uint32_t eqbits = 0, eqall = 1, cntbits = 0;
+            uint32_t eqbits = 0, eqall = 1, cntbits = 0, wide = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 sched_fence();
@@ -668,21 +673,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 r.mx2[j] = mx2;
                 const bool P2S = !inv2 && mn2 != mx2;
                 sI2 += P2S ? 1u : 0u;
-                // ---- snapshot candidate (snapshot.rs:108-156): every difference inside node j is bounded by
-                //      mx2-mn2, below 128 they all take one byte and nothing needs classifying
-                if (PADDED || (mx2 - mn2) >= 128) {
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq++) {
-                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                        sMax.add(zz32(inv1[qq] ? mx2 : mx2 - mx1[qq]), P2S);
-                        sMin.add(zz32(mn1[qq] - mn2), P1S[qq]);
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const bool inv0 = inval(rq + (i >> 1), cq + (i & 1));
-                            sMax.add(zz32(inv0 ? mx1[qq] : mx1[qq] - t16[4 * qq + i]), P1S[qq]);
-                        }
-                    }
-                }
+                // (the snapshot candidate's byte classes are computed lazily: see classes_pass below)
                 // ---- log candidate vs. the open block's snapshot (log.rs:112-165, 725-817) ----
                 if (have_s) {
                     int32_t s16[16];
@@ -706,9 +697,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         const bool P1L = !inv1[qq] && mn1[qq] != mx1[qq] && !eq1[qq];  // log.rs:137-152
                         lI1 += P1L ? 1u : 0u;
                         cntbits += (P1L ? 1u : 0u) << (16 + 3 * j);  // bits 16..27: internal quads per j, log
-                        lMax.add4(zz32(d[0]), zz32(d[1]), zz32(d[2]), zz32(d[3]), P1L);  // cells: t - s
-                        pend1.add(zz32(inv1[qq] ? 0 : mx1[qq] - smx1[qq]), true);         // log.rs:133
-                        lMin.add(zz32(mn1[qq] - smn1[qq]), P1L);                          // log.rs:148
+#pragma unroll
+                        for (int i = 0; i < 4; i++) lMax.add1(d[i], P1L);            // cells: t - s
+                        pend1.add1(inv1[qq] ? 0 : mx1[qq] - smx1[qq], true);          // log.rs:133
+                        lMin.add1(mn1[qq] - smn1[qq], P1L);                           // log.rs:148
                     }
                     const int32_t smn2 = min4(smn1[0], smn1[1], smn1[2], smn1[3]);
                     const int32_t smx2 = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
@@ -718,8 +710,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const bool P2L = !inv2 && mn2 != mx2 && !eq2;
                     lI2 += P2L ? 1u : 0u;
                     lMax.add(pend1, P2L);
-                    lPend2.add(zz32(inv2 ? 0 : mx2 - smx2), true);
-                    lMin.add(zz32(mn2 - smn2), P2L);
+                    lPend2.add1(inv2 ? 0 : mx2 - smx2, true);
+                    lMin.add1(mn2 - smn2, P2L);
                     r.smn2[j] = smn2;
                     r.smx2[j] = smx2;
                     eqbits |= (eq2 ? 1u : 0u) << j;
@@ -729,31 +721,28 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             const int32_t mn3 = min4(r.mn2[0], r.mn2[1], r.mn2[2], r.mn2[3]);
             const int32_t mx3 = max4(r.mx2[0], r.mx2[1], r.mx2[2], r.mx2[3]);
             const bool P3S = !inv3 && mn3 != mx3;
-            if (PADDED || (mx3 - mn3) >= 128) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
-                    sMax.add(zz32(inv2 ? mx3 : mx3 - r.mx2[j]), P3S);
-                    sMin.add(zz32(r.mn2[j] - mn3), !inv2 && r.mn2[j] != r.mx2[j]);
-                }
-            }
             sh.tmin[tid] = mn3;
             sh.tmax[tid] = mx3;
             r.sc[0] = (uint64_t)sI1 | ((uint64_t)sI2 << 16);
-            r.sc[2] = sMax.pack18();
-            r.sc[3] = sMin.pack16();
+            r.sc[2] = 0;  // snapshot byte classes: lazily, only when the exact snapshot size matters
+            r.sc[3] = 0;
+            (void)P3S;
             if (have_s) {
                 const int32_t smn3 = min4(r.smn2[0], r.smn2[1], r.smn2[2], r.smn2[3]);
                 const int32_t smx3 = max4(r.smx2[0], r.smx2[1], r.smx2[2], r.smx2[3]);
                 const bool eq3 = eqall && df2[0] == df2[1] && df2[0] == df2[2] && df2[0] == df2[3];
                 const bool PL3 = !inv3 && mn3 != mx3 && !eq3;
                 lMax.add(lPend2, PL3);
+                // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: below 2^15 in magnitude none of them
+                // needs a third byte; otherwise the exact classes_pass is requested (bit 60 of the top pack)
+                const int32_t lo_b = mn3 - smx3, hi_b = mx3 - smn3;
+                wide = (lo_b < -32768 || hi_b > 32767) ? 1u : 0u;
                 sh.smin[tid] = smn3;
                 sh.smax[tid] = smx3;
                 sh.diff[tid] = df2[0];
                 sh.eq[tid] = eq3 ? 1u : 0u;
             }
-            r.flags = eqbits | cntbits;
+            r.flags = eqbits | cntbits | (wide << 28);
             r.sc[4] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
             r.sc[6] = lMax.pack18();
             r.sc[7] = lMin.pack16();
@@ -824,16 +813,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         // ================= phase 3: own node + owned top nodes, then the scan ==========================
         ex.par([&](int tid, EncRegs& r) {
             uint64_t sLo = r.sc[0], sTop = 0, lLo = r.sc[4], lTop = 0;
-            Cls sMax, sMin, lMax, lMin;
+            Cls lMax, lMin;
 #pragma unroll
             for (int h = 3; h <= H; h++) {
                 const uint32_t span = 1u << (2 * (h - 3));  // threads under one node of height h
                 if (((uint32_t)tid & (span - 1)) != 0) break;
                 const uint32_t j = (uint32_t)tid >> (2 * (h - 3));
-                const bool visS = (h == H) ? true : PS(h + 1, j >> 2);
                 const bool pS = PS(h, j);
-                sMax.add(zz32(snap_vmax(h, j)), visS);
-                sMin.add(zz32(snap_vmin(h, j)), pS);
                 if (pS) {
                     if (h == 3) sLo += 1ull << 30;
                     else sTop += packTop(h);
@@ -851,10 +837,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
             r.sc[0] = sLo;
             r.sc[1] = sTop;
-            r.sc[2] += sMax.pack18();
-            r.sc[3] += sMin.pack16();
             r.sc[4] = lLo;
-            r.sc[5] = lTop;
+            r.sc[5] = lTop + ((uint64_t)((r.flags >> 28) & 1u) << 40);  // blocks asking for the exact log classes
             r.sc[6] += lMax.pack18();
             r.sc[7] += lMin.pack16();
         });
@@ -862,20 +846,100 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         ex.template reduce<8>();
         ex.stamp(3);  // totals of all 8 fields
 
+        // Exact byte classes of EVERY value of one candidate (0 = snapshot, 1 = log): a second streaming pass over
+        // the tile with compact rolled loops, run only when the exact figure matters (see phase 4).  Totals end up
+        // in sh.tot[2] (Lmax, pack18) and sh.tot[3] (Lmin, pack16).
+        auto classes_pass = [&](const int which) {
+            ex.par_nosync([&](int tid, EncRegs& r) {
+                uint32_t r0, c0;
+                blk_origin(tid, r0, c0);
+                int32_t lerr = 0;
+                Cls vMax, vMin;
+#pragma unroll 1
+                for (int h = 3; h <= H; h++) {  // own node + owned top nodes
+                    const uint32_t span = 1u << (2 * (h - 3));
+                    if (((uint32_t)tid & (span - 1)) != 0) break;
+                    const uint32_t j = (uint32_t)tid >> (2 * (h - 3));
+                    if (which == 0) {
+                        vMax.add(zz32(snap_vmax(h, j)), (h == H) ? true : PS(h + 1, j >> 2));
+                        vMin.add(zz32(snap_vmin(h, j)), PS(h, j));
+                    } else {
+                        vMax.add(zz32(log_vmax(h, j)), (h == H) ? true : PL(h + 1, j >> 2));
+                        vMin.add(zz32(log_vmin(h, j)), PL(h, j));
+                    }
+                }
+                const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
+                const bool inv3 = inval(r0, c0);
+                const bool P3 = !inv3 && mn3 != mx3 && (which == 0 || sh.eq[tid] == 0);
+#pragma unroll 1
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                    const bool inv2 = inval(rj, cj);
+                    const int32_t mn2 = sel4(r.mn2, j), mx2 = sel4(r.mx2, j);
+                    const bool unif2 = inv2 || mn2 == mx2;
+                    bool P2;
+                    if (which == 0) {
+                        P2 = !unif2;
+                        vMax.add(zz32(inv2 ? mx3 : mx3 - mx2), P3);
+                        vMin.add(zz32(mn2 - mn3), P2);
+                    } else {
+                        P2 = !unif2 && ((r.flags >> j) & 1u) == 0;
+                        vMax.add(zz32(inv2 ? 0 : mx2 - sel4(r.smx2, j)), P3);
+                        vMin.add(zz32(mn2 - sel4(r.smn2, j)), P2);
+                    }
+                    if (!P2) continue;
+                    int32_t t16[16], s16[16];
+                    load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
+                    if (which != 0) load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                        const bool inv1 = inval(rq, cq);
+                        const int32_t mn1 = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                        const int32_t mx1 = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                        const bool unif1 = inv1 || mn1 == mx1;
+                        if (which == 0) {
+                            vMax.add(zz32(inv1 ? mx2 : mx2 - mx1), true);
+                            vMin.add(zz32(mn1 - mn2), !unif1);
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                vMax.add(zz32(inval(rq + (i >> 1), cq + (i & 1)) ? mx1 : mx1 - t16[4 * qq + i]), !unif1);
+                        } else {
+                            int32_t d[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
+                            const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                            const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                            const bool P1 = !unif1 && !(d[0] == d[1] && d[0] == d[2] && d[0] == d[3]);
+                            vMax.add(zz32(inv1 ? 0 : mx1 - smx1), true);
+                            vMin.add(zz32(mn1 - smn1), P1);
+#pragma unroll
+                            for (int i = 0; i < 4; i++) vMax.add(zz32(d[i]), P1);
+                        }
+                    }
+                }
+                r.sc[2] = vMax.pack18();
+                r.sc[3] = vMin.pack16();
+            });
+            ex.template reduce<2, 2>();
+        };
+
         // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
         Totals<C> TS, TL;
         TS.from(ex.uni(sh.tot[0]), ex.uni(sh.tot[1]));
-        const uint64_t sx = ex.uni(sh.tot[2]), sn = ex.uni(sh.tot[3]);
-        const DacLayout SV = dac_layout(13 + bitmap_size(TS.LT), TS.N0, (uint32_t)(sx & 0x3ffff),
-                                        (uint32_t)((sx >> 18) & 0x3ffff), (uint32_t)((sx >> 36) & 0x3ffff));
-        const DacLayout SM = dac_layout(SV.end, TS.M0, (uint32_t)(sn & 0xffff), (uint32_t)((sn >> 16) & 0xffff),
-                                        (uint32_t)((sn >> 32) & 0xffff));
-        const uint32_t snap_size = SM.end;  // snapshot.rs:87-92
-        DacLayout LV = SV, LM = SM;
+        DacLayout LV{}, LM{};
         uint32_t log_size = 0, log_eq_off = 0;
+        const bool cap254 = have_s && (blk_count - 1 == 254);  // chunk.rs:62 (checked first)
         if (have_s) {
-            TL.from(ex.uni(sh.tot[4]), ex.uni(sh.tot[5]));
-            const uint64_t lx = ex.uni(sh.tot[6]), ln = ex.uni(sh.tot[7]);
+            const uint64_t ltop = ex.uni(sh.tot[5]);
+            TL.from(ex.uni(sh.tot[4]), ltop);
+            uint64_t lx = ex.uni(sh.tot[6]), ln = ex.uni(sh.tot[7]);
+            if ((ltop >> 40) != 0) {  // some block has log values that may need 3+ bytes: count exactly
+                classes_pass(1);
+                lx = ex.uni(sh.tot[2]);
+                ln = ex.uni(sh.tot[3]);
+            }
             log_eq_off = 13 + bitmap_size(TL.LT);
             LV = dac_layout(log_eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, (uint32_t)(lx & 0x3ffff),
                             (uint32_t)((lx >> 18) & 0x3ffff), (uint32_t)((lx >> 36) & 0x3ffff));
@@ -883,7 +947,23 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                             (uint32_t)((ln >> 32) & 0xffff));
             log_size = LM.end;  // log.rs:95-97
         }
-        const bool as_snapshot = !have_s || (blk_count - 1 == 254) || snap_size <= log_size;
+        // Snapshot size (snapshot.rs:87-92).  With every value at its minimum of one byte it is a lower bound that
+        // costs nothing; only if that bound does not already exceed the log's size (or the snapshot is taken
+        // regardless) are the exact byte classes counted.
+        const uint32_t sbase = 13 + bitmap_size(TS.LT);
+        DacLayout SV = dac_layout(sbase, TS.N0, 0, 0, 0);
+        DacLayout SM = dac_layout(SV.end, TS.M0, 0, 0, 0);
+        uint32_t snap_size = SM.end;
+        if (!have_s || cap254 || snap_size <= log_size) {
+            classes_pass(0);
+            const uint64_t sx = ex.uni(sh.tot[2]), sn = ex.uni(sh.tot[3]);
+            SV = dac_layout(sbase, TS.N0, (uint32_t)(sx & 0x3ffff), (uint32_t)((sx >> 18) & 0x3ffff),
+                            (uint32_t)((sx >> 36) & 0x3ffff));
+            SM = dac_layout(SV.end, TS.M0, (uint32_t)(sn & 0xffff), (uint32_t)((sn >> 16) & 0xffff),
+                            (uint32_t)((sn >> 32) & 0xffff));
+            snap_size = SM.end;
+        }
+        const bool as_snapshot = !have_s || cap254 || snap_size <= log_size;
 
         uint32_t hdr_patch_off = 0, hdr_patch_val = 0;
         bool do_patch = false;

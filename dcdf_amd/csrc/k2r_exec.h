@@ -69,13 +69,13 @@ struct GpuExec {
     }
 
     // workgroup sum of r.sc[0..NF) -> sh.tot[0..NF) (no prefixes): wave butterfly + one LDS atomic per wave
-    template <int NF>
+    template <int NF, int F0 = 0>
     __device__ __forceinline__ void reduce() {
         constexpr int W = NT < 64 ? NT : 64;
-        for (int f = tid; f < NF; f += NT) sh.tot[f] = 0;  // NT may be smaller than NF (sidelen 8, 16)
+        for (int f = F0 + tid; f < F0 + NF; f += NT) sh.tot[f] = 0;  // NT may be smaller than NF (sidelen 8, 16)
         lds_barrier();
 #pragma unroll
-        for (int f = 0; f < NF; f++) {
+        for (int f = F0; f < F0 + NF; f++) {
             uint64_t v = r.sc[f];
 #pragma unroll
             for (int d = W / 2; d >= 1; d >>= 1) v += __shfl_xor((unsigned long long)v, d, 64);
@@ -154,9 +154,9 @@ struct SimExec {
     void stamp(int) {}
     template <class T>
     T uni(T v) const { return v; }
-    template <int NF>
+    template <int NF, int F0 = 0>
     void reduce() {
-        for (int f = 0; f < NF; f++) {
+        for (int f = F0; f < F0 + NF; f++) {
             uint64_t run = 0;
             for (int t = 0; t < NT; t++) run += regs[t].sc[f];
             sh.tot[f] = run;
