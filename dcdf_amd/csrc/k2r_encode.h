@@ -478,6 +478,57 @@ K2R_HD void bitmap_finish_write(EX& ex, const uint32_t* bm, uint32_t nbits, uint
     });
 }
 
+// One pass over up to four LDS bitmaps at once (T, eqB, and plane 0 of both Dacs): a single 4-field workgroup
+// scan of per-thread popcounts, then every thread serializes its own word range of each bitmap -- header,
+// rank index (bitmap.rs:97-104) and big-endian words (bitmap.rs:128-138) -- and leaves the per-word prefix
+// (needed for ranks on the Dac continuation bitmaps) in `pref`.
+struct BmJob {
+    const uint32_t* bm;  // LDS words
+    uint32_t nbits;
+    uint32_t* pref;      // LDS, may be null
+    uint8_t* dst;        // serialized BitMap goes here; null = bitmap absent
+};
+K2R_HD void gstore32u(uint8_t* p, uint32_t v);
+template <class C, class EX>
+K2R_HD void bitmaps_finish4(EX& ex, const BmJob (&J)[4]) {
+    constexpr int NT = C::NT;
+    ex.par_nosync([&](int tid, EncRegs& r) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            uint32_t sum = 0;
+            if (J[f].dst) {
+                const uint32_t W = (J[f].nbits + 31) / 32, CH = (W + NT - 1) / NT, w0 = (uint32_t)tid * CH;
+                for (uint32_t w = w0; w < w0 + CH && w < W; w++) sum += popc32(J[f].bm[w]);
+            }
+            r.sc[f] = sum;
+        }
+    });
+    ex.template scan<4>();
+    ex.par([&](int tid, EncRegs& r) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            if (!J[f].dst) continue;
+            const uint32_t nbits = J[f].nbits, W = (nbits + 31) / 32, CH = (W + NT - 1) / NT, w0 = (uint32_t)tid * CH;
+            const uint32_t nidx = nbits / 128;  // bitmap.rs:70
+            uint8_t* const dst = J[f].dst;
+            uint8_t* const wd = dst + 8 + 4 * nidx;
+            if (tid == 0) {
+                gstore32u(dst, __builtin_bswap32(nbits));
+                gstore32u(dst + 4, __builtin_bswap32(4u));  // k, bitmap.rs:69,130
+            }
+            uint32_t run = (uint32_t)r.sc[f];
+            for (uint32_t w = w0; w < w0 + CH && w < W; w++) {
+                const uint32_t x = J[f].bm[w];
+                if (J[f].pref) J[f].pref[w] = run;
+                run += popc32(x);
+                gstore32u(wd + 4 * w, __builtin_bswap32(x));
+                if ((w & 3u) == 3u && (w >> 2) < nidx) gstore32u(dst + 8 + 4 * (w >> 2), __builtin_bswap32(run));
+            }
+            if (J[f].pref && w0 < W && w0 + CH >= W) J[f].pref[W] = run;  // total, for rank(len)
+        }
+    });
+}
+
 // ---- emission sink ---------------------------------------------------------------------------------
 // One Dac being written: plane-0 bytes go straight to memory, longer values go to the overflow list.
 struct DacSink {
@@ -723,9 +774,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             const bool P3S = !inv3 && mn3 != mx3;
             sh.tmin[tid] = mn3;
             sh.tmax[tid] = mx3;
+            // scan/reduce fields: [0] snapshot lo pack, [1] snapshot top pack | log c1(max) << 30 | log c1(min) << 48,
+            //                     [2] log lo pack, [3] log top pack | "wide" requests << 40
             r.sc[0] = (uint64_t)sI1 | ((uint64_t)sI2 << 16);
-            r.sc[2] = 0;  // snapshot byte classes: lazily, only when the exact snapshot size matters
-            r.sc[3] = 0;
             (void)P3S;
             if (have_s) {
                 const int32_t smn3 = min4(r.smn2[0], r.smn2[1], r.smn2[2], r.smn2[3]);
@@ -743,9 +794,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.eq[tid] = eq3 ? 1u : 0u;
             }
             r.flags = eqbits | cntbits | (wide << 28);
-            r.sc[4] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
-            r.sc[6] = lMax.pack18();
-            r.sc[7] = lMin.pack16();
+            r.sc[2] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
+            r.sc[1] = ((uint64_t)lMax.c1 << 30) | ((uint64_t)lMin.c1 << 48);
             if (err != 0) ex.lds_min(&sh.err, err);
         });
         const int32_t perr = ex.uni(sh.err);
@@ -812,7 +862,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 
         // ================= phase 3: own node + owned top nodes, then the scan ==========================
         ex.par([&](int tid, EncRegs& r) {
-            uint64_t sLo = r.sc[0], sTop = 0, lLo = r.sc[4], lTop = 0;
+            uint64_t sLo = r.sc[0], sTop = 0, lLo = r.sc[2], lTop = 0;
+            uint32_t widetop = 0;
             Cls lMax, lMin;
 #pragma unroll
             for (int h = 3; h <= H; h++) {
@@ -827,8 +878,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 if (have_s) {
                     const bool visL = (h == H) ? true : PL(h + 1, j >> 2);
                     const bool pL = PL(h, j);
-                    lMax.add(zz32(log_vmax(h, j)), visL);
-                    lMin.add(zz32(log_vmin(h, j)), pL);
+                    const int32_t vx = log_vmax(h, j), vn = log_vmin(h, j);
+                    lMax.add1(vx, visL);
+                    lMin.add1(vn, pL);
+                    widetop |= ((visL && (vx < -32768 || vx > 32767)) || (pL && (vn < -32768 || vn > 32767))) ? 1u : 0u;
                     if (pL) {
                         if (h == 3) lLo += 1ull << 30;
                         else lTop += packTop(h);
@@ -836,19 +889,17 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 }
             }
             r.sc[0] = sLo;
-            r.sc[1] = sTop;
-            r.sc[4] = lLo;
-            r.sc[5] = lTop + ((uint64_t)((r.flags >> 28) & 1u) << 40);  // blocks asking for the exact log classes
-            r.sc[6] += lMax.pack18();
-            r.sc[7] += lMin.pack16();
+            r.sc[1] += sTop + ((uint64_t)lMax.c1 << 30) + ((uint64_t)lMin.c1 << 48);
+            r.sc[2] = lLo;
+            r.sc[3] = lTop + ((uint64_t)(((r.flags >> 28) & 1u) + widetop) << 40);  // requests for the exact log classes
         });
         ex.stamp(2);  // phase 3: own/top nodes
-        ex.template reduce<8>();
-        ex.stamp(3);  // totals of all 8 fields
+        ex.template reduce<4>();
+        ex.stamp(3);  // totals of the 4 packed fields
 
         // Exact byte classes of EVERY value of one candidate (0 = snapshot, 1 = log): a second streaming pass over
         // the tile with compact rolled loops, run only when the exact figure matters (see phase 4).  Totals end up
-        // in sh.tot[2] (Lmax, pack18) and sh.tot[3] (Lmin, pack16).
+        // in sh.tot[4] (Lmax, pack18) and sh.tot[5] (Lmin, pack16).
         auto classes_pass = [&](const int which) {
             ex.par_nosync([&](int tid, EncRegs& r) {
                 uint32_t r0, c0;
@@ -919,26 +970,27 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         }
                     }
                 }
-                r.sc[2] = vMax.pack18();
-                r.sc[3] = vMin.pack16();
+                r.sc[4] = vMax.pack18();
+                r.sc[5] = vMin.pack16();
             });
-            ex.template reduce<2, 2>();
+            ex.template reduce<2, 4>();
         };
 
         // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
         Totals<C> TS, TL;
-        TS.from(ex.uni(sh.tot[0]), ex.uni(sh.tot[1]));
+        const uint64_t tot1 = ex.uni(sh.tot[1]);
+        TS.from(ex.uni(sh.tot[0]), tot1 & 0x3fffffffull);
         DacLayout LV{}, LM{};
         uint32_t log_size = 0, log_eq_off = 0;
         const bool cap254 = have_s && (blk_count - 1 == 254);  // chunk.rs:62 (checked first)
         if (have_s) {
-            const uint64_t ltop = ex.uni(sh.tot[5]);
-            TL.from(ex.uni(sh.tot[4]), ltop);
-            uint64_t lx = ex.uni(sh.tot[6]), ln = ex.uni(sh.tot[7]);
+            const uint64_t ltop = ex.uni(sh.tot[3]);
+            TL.from(ex.uni(sh.tot[2]), ltop & 0xffffffffffull);
+            uint64_t lx = (tot1 >> 30) & 0x3ffff, ln = tot1 >> 48;  // only "> 1 byte" counts are kept inline
             if ((ltop >> 40) != 0) {  // some block has log values that may need 3+ bytes: count exactly
                 classes_pass(1);
-                lx = ex.uni(sh.tot[2]);
-                ln = ex.uni(sh.tot[3]);
+                lx = ex.uni(sh.tot[4]);
+                ln = ex.uni(sh.tot[5]);
             }
             log_eq_off = 13 + bitmap_size(TL.LT);
             LV = dac_layout(log_eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, (uint32_t)(lx & 0x3ffff),
@@ -956,7 +1008,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         uint32_t snap_size = SM.end;
         if (!have_s || cap254 || snap_size <= log_size) {
             classes_pass(0);
-            const uint64_t sx = ex.uni(sh.tot[2]), sn = ex.uni(sh.tot[3]);
+            const uint64_t sx = ex.uni(sh.tot[4]), sn = ex.uni(sh.tot[5]);
             SV = dac_layout(sbase, TS.N0, (uint32_t)(sx & 0x3ffff), (uint32_t)((sx >> 18) & 0x3ffff),
                             (uint32_t)((sx >> 36) & 0x3ffff));
             SM = dac_layout(SV.end, TS.M0, (uint32_t)(sn & 0xffff), (uint32_t)((sn >> 16) & 0xffff),
@@ -993,8 +1045,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         const DacLayout DM = as_snapshot ? SM : LM;
         // exclusive prefixes of the winner's internal counts (positions)
         ex.par_nosync([&](int, EncRegs& r) {
-            r.sc[0] = as_snapshot ? r.sc[0] : r.sc[4];
-            r.sc[1] = as_snapshot ? r.sc[1] : r.sc[5];
+            r.sc[0] = as_snapshot ? r.sc[0] : r.sc[2];
+            r.sc[1] = as_snapshot ? (r.sc[1] & 0x3fffffffull) : (r.sc[3] & 0xffffffffffull);
         });
         ex.template scan<2>();
 
@@ -1219,7 +1271,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         dac_finish<C>(ex, DV, io, sh.bmV[0], sh.bmV[1], sh.prefV, listV, &sh.nlistV);
         ex.stamp(8);  // Lmax Dac: bitmaps + planes >= 1
         dac_finish<C>(ex, DM, io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
-        ex.stamp(9);  // Lmin Dac
+        ex.stamp(9);  // Lmin Dac: planes >= 1
 
         off += isize;
         blk_count++;
