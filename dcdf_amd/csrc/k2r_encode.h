@@ -41,6 +41,8 @@ struct EncCfg {
     static constexpr int NT = NBLK;                      // one thread per block
     static constexpr int NW = NT < 64 ? 1 : NT / 64;
     static constexpr int NTOP = ((1 << (2 * (H - 2))) - 1) / 3;  // nodes at heights 3..H
+    static constexpr int NTOPX = NTOP - (1 << (2 * (H - 3)));     // nodes at heights 4..H (each gets its own worker thread)
+    static constexpr int TBW = (NTOPX + 31) / 32 + 1;             // words of a bitset over them
     static constexpr int MAXV = ((1 << (2 * (H + 1))) - 1) / 3;  // all nodes        (|Lmax|)
     static constexpr int MAXT = ((1 << (2 * H)) - 1) / 3;        // nodes w/ children (|T|, max |Lmin|)
     static constexpr int WV = (MAXV + 31) / 32;
@@ -63,6 +65,8 @@ struct EncShared {
     // quads before the item) and internal quads (key = blk<<4|j<<2|qq)
     uint32_t L2[4 * C::NBLK];
     uint16_t L1[16 * C::NBLK];
+    uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
+    uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
     uint32_t nlistV, nlistM;
     int32_t err;
     uint32_t work;
@@ -353,6 +357,20 @@ K2R_HD DacLayout dac_layout(uint32_t base, uint32_t n0, uint32_t n1, uint32_t n2
     return L;
 }
 
+// number of set bits in positions [lo, hi) of a small LDS bitset
+K2R_HD uint32_t bits_count(const uint32_t* w, uint32_t lo, uint32_t hi) {
+    uint32_t n = 0;
+    for (uint32_t i = lo >> 5; i <= ((hi + 31) >> 5) && (i << 5) < hi; i++) {
+        uint32_t x = w[i];
+        const uint32_t b0 = i << 5;
+        if (lo > b0) x &= 0xffffffffu << (lo - b0);
+        if (hi < b0 + 32) x &= (hi > b0) ? (0xffffffffu >> (b0 + 32 - hi)) : 0u;
+        n += popc32(x);
+    }
+    return n;
+}
+K2R_HD bool bit_test(const uint32_t* w, uint32_t b) { return (w[b >> 5] >> (b & 31)) & 1u; }
+
 template <class C>
 struct Totals {
     uint32_t Ni[C::H + 2];    // internal nodes per height (index 1..H)
@@ -360,6 +378,7 @@ struct Totals {
     uint32_t offI[C::H + 2];  // Lmin index of the first internal node of height h
     uint32_t offZ[C::H + 2];  // eqB index of the first T=0 node of height h
     uint32_t LT, N0, M0;
+    // internal counts of heights 1..3 come from the reduced lo pack, those of heights 4..H from the bitset
     K2R_HD void from(uint64_t lo, uint64_t top) {
         constexpr int H = C::H;
 #pragma unroll
@@ -794,6 +813,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.eq[tid] = eq3 ? 1u : 0u;
             }
             r.flags = eqbits | cntbits | (wide << 28);
+            if (tid < C::TBW) {
+                sh.tbS[tid] = 0;
+                sh.tbL[tid] = 0;
+            }
             r.sc[2] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
             r.sc[1] = ((uint64_t)lMax.c1 << 30) | ((uint64_t)lMin.c1 << 48);
             if (err != 0) ex.lds_min(&sh.err, err);
@@ -860,20 +883,29 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             return sh.tmin[a] - sh.smin[a];  // log.rs:148
         };
 
-        // ================= phase 3: own node + owned top nodes, then the scan ==========================
-        ex.par([&](int tid, EncRegs& r) {
-            uint64_t sLo = r.sc[0], sTop = 0, lLo = r.sc[2], lTop = 0;
-            uint32_t widetop = 0;
-            Cls lMax, lMin;
+        // worker thread n < NTOPX looks after top node n (heights 4..H, level order); bit index == n
+        auto top_decode = [&](uint32_t n, int& h, uint32_t& j) {
+            h = 4;
 #pragma unroll
-            for (int h = 3; h <= H; h++) {
-                const uint32_t span = 1u << (2 * (h - 3));  // threads under one node of height h
-                if (((uint32_t)tid & (span - 1)) != 0) break;
-                const uint32_t j = (uint32_t)tid >> (2 * (h - 3));
-                const bool pS = PS(h, j);
-                if (pS) {
+            for (int k = 4; k < H; k++)
+                if (n >= (uint32_t)(C::top_off(k + 1) - C::NBLK)) h = k + 1;
+            j = n - (uint32_t)(C::top_off(h) - C::NBLK);
+        };
+        auto tbit = [&](int h, uint32_t j) -> uint32_t { return (uint32_t)(C::top_off(h) - C::NBLK) + j; };
+
+        // ================= phase 3: own node + (for the first NTOPX threads) one top node each ==========
+        ex.par([&](int tid, EncRegs& r) {
+            uint64_t sLo = r.sc[0], lLo = r.sc[2];
+            uint32_t wide = (r.flags >> 28) & 1u;
+            Cls lMax, lMin;
+            uint64_t sTop = 0, lTop = 0;
+            auto node = [&](int h, uint32_t j) {
+                if (PS(h, j)) {
                     if (h == 3) sLo += 1ull << 30;
-                    else sTop += packTop(h);
+                    else {
+                        ex.lds_or(&sh.tbS[tbit(h, j) >> 5], 1u << (tbit(h, j) & 31));
+                        sTop += packTop(h);
+                    }
                 }
                 if (have_s) {
                     const bool visL = (h == H) ? true : PL(h + 1, j >> 2);
@@ -881,17 +913,29 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const int32_t vx = log_vmax(h, j), vn = log_vmin(h, j);
                     lMax.add1(vx, visL);
                     lMin.add1(vn, pL);
-                    widetop |= ((visL && (vx < -32768 || vx > 32767)) || (pL && (vn < -32768 || vn > 32767))) ? 1u : 0u;
+                    wide |= ((visL && (vx < -32768 || vx > 32767)) || (pL && (vn < -32768 || vn > 32767))) ? 1u : 0u;
                     if (pL) {
                         if (h == 3) lLo += 1ull << 30;
-                        else lTop += packTop(h);
+                        else {
+                            ex.lds_or(&sh.tbL[tbit(h, j) >> 5], 1u << (tbit(h, j) & 31));
+                            lTop += packTop(h);
+                        }
                     }
                 }
+            };
+            node(3, (uint32_t)tid);
+            if (tid < C::NTOPX) {
+                int h;
+                uint32_t j;
+                top_decode((uint32_t)tid, h, j);
+                node(h, j);
             }
+            // fields: [0] snapshot lo pack, [1] snapshot top pack | log c1(max) << 30 | log c1(min) << 48,
+            //         [2] log lo pack, [3] log top pack | wide requests << 40
             r.sc[0] = sLo;
             r.sc[1] += sTop + ((uint64_t)lMax.c1 << 30) + ((uint64_t)lMin.c1 << 48);
             r.sc[2] = lLo;
-            r.sc[3] = lTop + ((uint64_t)(((r.flags >> 28) & 1u) + widetop) << 40);  // requests for the exact log classes
+            r.sc[3] = lTop + ((uint64_t)wide << 40);
         });
         ex.stamp(2);  // phase 3: own/top nodes
         ex.template reduce<4>();
@@ -901,16 +945,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         // the tile with compact rolled loops, run only when the exact figure matters (see phase 4).  Totals end up
         // in sh.tot[4] (Lmax, pack18) and sh.tot[5] (Lmin, pack16).
         auto classes_pass = [&](const int which) {
+#ifdef K2R_SIM_TRACE
+            if (EX::kSim) __builtin_printf("classes_pass(%d) inst=%u\n", which, inst);
+#endif
             ex.par_nosync([&](int tid, EncRegs& r) {
                 uint32_t r0, c0;
                 blk_origin(tid, r0, c0);
                 int32_t lerr = 0;
                 Cls vMax, vMin;
-#pragma unroll 1
-                for (int h = 3; h <= H; h++) {  // own node + owned top nodes
-                    const uint32_t span = 1u << (2 * (h - 3));
-                    if (((uint32_t)tid & (span - 1)) != 0) break;
-                    const uint32_t j = (uint32_t)tid >> (2 * (h - 3));
+                auto cnode = [&](int h, uint32_t j) {
                     if (which == 0) {
                         vMax.add(zz32(snap_vmax(h, j)), (h == H) ? true : PS(h + 1, j >> 2));
                         vMin.add(zz32(snap_vmin(h, j)), PS(h, j));
@@ -918,6 +961,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         vMax.add(zz32(log_vmax(h, j)), (h == H) ? true : PL(h + 1, j >> 2));
                         vMin.add(zz32(log_vmin(h, j)), PL(h, j));
                     }
+                };
+                cnode(3, (uint32_t)tid);
+                if (tid < C::NTOPX) {
+                    int h;
+                    uint32_t j;
+                    top_decode((uint32_t)tid, h, j);
+                    cnode(h, j);
                 }
                 const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
                 const bool inv3 = inval(r0, c0);
@@ -984,10 +1034,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         uint32_t log_size = 0, log_eq_off = 0;
         const bool cap254 = have_s && (blk_count - 1 == 254);  // chunk.rs:62 (checked first)
         if (have_s) {
-            const uint64_t ltop = ex.uni(sh.tot[3]);
-            TL.from(ex.uni(sh.tot[2]), ltop & 0xffffffffffull);
+            const uint64_t tot3 = ex.uni(sh.tot[3]);
+            TL.from(ex.uni(sh.tot[2]), tot3 & 0x3fffffffull);
             uint64_t lx = (tot1 >> 30) & 0x3ffff, ln = tot1 >> 48;  // only "> 1 byte" counts are kept inline
-            if ((ltop >> 40) != 0) {  // some block has log values that may need 3+ bytes: count exactly
+            if ((tot3 >> 40) != 0) {  // some log value may need 3+ bytes: count exactly
                 classes_pass(1);
                 lx = ex.uni(sh.tot[4]);
                 ln = ex.uni(sh.tot[5]);
@@ -1046,9 +1096,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         // exclusive prefixes of the winner's internal counts (positions)
         ex.par_nosync([&](int, EncRegs& r) {
             r.sc[0] = as_snapshot ? r.sc[0] : r.sc[2];
-            r.sc[1] = as_snapshot ? (r.sc[1] & 0x3fffffffull) : (r.sc[3] & 0xffffffffffull);
         });
-        ex.template scan<2>();
+        ex.template scan<1>();
 
         // ================= phase 5: emission of the winner ===============================================
         // 5a. clear bitmaps, save prefixes, header
@@ -1061,8 +1110,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV[0][w] = 0;
             for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
             r.pf_lo = r.sc[0];
-            r.pf_top = r.sc[1];
             if (tid == 0) {
+#pragma unroll
+                for (int h = 0; h <= H; h++) {
+                    sh.ttV[h] = TT.offV[h];
+                    sh.ttI[h] = TT.offI[h];
+                    sh.ttZ[h] = TT.offZ[h];
+                }
                 sh.nlistV = 0;
                 sh.nlistM = 0;
                 if (do_patch) out[hdr_patch_off] = (uint8_t)hdr_patch_val;
@@ -1087,38 +1141,41 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         ex.par([&](int tid, EncRegs& r) {
             uint32_t r0, c0;
             blk_origin(tid, r0, c0);
-            const uint64_t pLo = r.pf_lo, pTop = r.pf_top;
+            const uint64_t pLo = r.pf_lo;
 
-            // -- top nodes owned by this thread, and its own height-3 node --
-#pragma unroll
-            for (int h = 3; h <= H; h++) {
-                const uint32_t span = 1u << (2 * (h - 3));
-                if (((uint32_t)tid & (span - 1)) != 0) break;
-                const uint32_t j = (uint32_t)tid >> (2 * (h - 3));
-                const bool vis = (h == H) ? true : (as_snapshot ? PS(h + 1, j >> 2) : PL(h + 1, j >> 2));
-                if (!vis) continue;
-                const bool p = as_snapshot ? PS(h, j) : PL(h, j);
-                // rank of the parent among internal nodes of height h+1: the exclusive prefix of this
-                // thread counts the parent itself unless this thread owns it (j & 3 == 0)
+            // -- this thread's own height-3 node and, for the first NTOPX threads, one top node each --
+            const uint32_t* const tb = as_snapshot ? sh.tbS : sh.tbL;
+            auto enode = [&](int h, uint32_t j) {
+                const bool vis = (h == H) ? true : bit_test(tb, tbit(h + 1, j >> 2));
+                if (!vis) return;
+                const bool p = (h == 3) ? (as_snapshot ? PS(3, j) : PL(3, j)) : bit_test(tb, tbit(h, j));
+                // level-order index: four children per internal parent, parents ranked among the internal nodes
                 uint32_t vrank = 0;
-                if (h < H) vrank = 4 * (unpackI(h + 1, pLo, pTop) - ((j & 3) ? 1u : 0u)) + (j & 3);
-                const uint32_t idx = TT.offV[h] + vrank;
-                const uint32_t irank = unpackI(h, pLo, pTop);
+                if (h < H) vrank = 4 * bits_count(tb, tbit(h + 1, 0), tbit(h + 1, j >> 2)) + (j & 3);
+                const uint32_t idx = sh.ttV[h] + vrank;
+                const uint32_t irank = (h == 3) ? unpackI(3, pLo, 0) : bits_count(tb, tbit(h, 0), tbit(h, j));
                 emit_val<0>(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
                 if (p) {
                     bm_set(ex, sh.bmT, guard_pos(ex, idx, 1, TT.LT, kGuardTOwn));
-                    emit_val<1>(ex, sinkM, TT.offI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
+                    emit_val<1>(ex, sinkM, sh.ttI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
                 } else if (!as_snapshot) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
-                    if (e) bm_set(ex, sh.bmE, guard_pos(ex, TT.offZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
+                    if (e) bm_set(ex, sh.bmE, guard_pos(ex, sh.ttZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
                 }
+            };
+            enode(3, (uint32_t)tid);
+            if (tid < C::NTOPX) {
+                int h;
+                uint32_t j;
+                top_decode((uint32_t)tid, h, j);
+                enode(h, j);
             }
 
             // -- the four height-2 children of this thread's block + the work list of internal height-2 nodes --
             const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
             const bool inv3 = inval(r0, c0);
-            const uint32_t E1 = unpackI(1, pLo, pTop), E2 = unpackI(2, pLo, pTop), E3 = unpackI(3, pLo, pTop);
+            const uint32_t E1 = unpackI(1, pLo, 0), E2 = unpackI(2, pLo, 0), E3 = unpackI(3, pLo, 0);
             const bool P3 = !inv3 && mn3 != mx3 && (as_snapshot || sh.eq[tid] == 0);
             if (P3) {
                 const uint32_t p2 = TT.offV[2] + 4 * E3;
