@@ -266,7 +266,8 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
             int32_t v[4];
 #if defined(__HIP_DEVICE_COMPILE__)
             typedef __attribute__((address_space(1))) const char* gptr;
-            const int4 a = *(__attribute__((address_space(1))) const int4*)((gptr)ib + (uint64_t)o * 4u);
+            const uint32_t ob = o << 2;  // 32-bit BYTE offset (< 2^31 by the host's VEC test): "saddr + voffset" form
+            const int4 a = *(__attribute__((address_space(1))) const int4*)((gptr)ib + ob);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
 #else
             for (int i = 0; i < 4; i++) v[i] = ib[o + i];
@@ -307,7 +308,8 @@ K2R_HD void load_quad(const TileArgs& ta, uint32_t inst, uint32_t rq, uint32_t c
             const uint32_t o = o0 + (uint32_t)dr * (uint32_t)ta.sr;
 #if defined(__HIP_DEVICE_COMPILE__)
             typedef __attribute__((address_space(1))) const char* gptr;
-            const int2 a = *(__attribute__((address_space(1))) const int2*)((gptr)ib + (uint64_t)o * 4u);
+            const uint32_t ob = o << 2;
+            const int2 a = *(__attribute__((address_space(1))) const int2*)((gptr)ib + ob);
             dst[2 * dr] = a.x;
             dst[2 * dr + 1] = a.y;
 #else
@@ -669,6 +671,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         morton_decode((uint32_t)tid, br, bc);
         r0 = br * 8;
         c0 = bc * 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Opaque to the optimizer on purpose: everything derived from the block origin (32 load addresses per
+        // instant) is loop-invariant across instants, and LICM would otherwise keep it all live in registers for the
+        // whole chunk -- i.e. spill it to scratch and reload it every instant.  Recomputing costs a few VALU ops.
+        asm volatile("" : "+v"(r0), "+v"(c0));
+#endif
     };
     // all-invalid test of the node whose top-left cell is (r,c)  (snapshot.rs:453-457)
     auto inval = [&](uint32_t r, uint32_t c) -> bool { return PADDED && (r >= ta.rows || c >= ta.cols); };

@@ -24,10 +24,12 @@ k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, c
     for (;;) {
         if (threadIdx.x == 0) sh.work = atomicAdd(queue, 1u);
         __syncthreads();
-        const uint32_t w = sh.work;
+        // read back through readfirstlane: the compiler must KNOW the tile index is wave-uniform, otherwise every field
+        // of TileArgs (base pointer, strides, shape...) is fetched per lane and all address arithmetic lands on the VALU
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.work);
         __syncthreads();
         if (w >= n) break;  // uniform: every wave of the workgroup leaves together
-        const uint32_t ti = order[w];
+        const uint32_t ti = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[w]);
         encode_chunk<C, PADDED, VEC>(ex, tiles[ti], &results[ti], listV, listM);
     }
 }
