@@ -69,3 +69,48 @@ extern "C" int dcdf_synth_fill(void* dst_device, int32_t dtype, uint64_t seed, i
     K2R_HIP(hipDeviceSynchronize());
     return DCDF_OK;
 }
+
+
+// ---- PMC calibration (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own access
+// pattern before trusting an absolute") --------------------------------------------------------------------
+// Reads n_tiles dense [instants,256,256] int32 tiles ONCE with exactly the encoder's access pattern (thread =
+// Morton 8x8 block, four 16-byte row pieces per 4x4 sub-block) and folds them into a checksum, so that
+// rocprofv3's FETCH_SIZE for this launch can be compared with the known byte count.
+namespace k2r {
+__global__ void __launch_bounds__(1024)
+k_calib_read(const int32_t* __restrict__ base, uint32_t n_tiles, uint32_t instants, unsigned long long* __restrict__ sink) {
+    uint32_t br, bc;
+    morton_decode(threadIdx.x, br, bc);
+    const uint32_t r0 = br * 8, c0 = bc * 8;
+    unsigned long long acc = 0;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        for (uint32_t i = 0; i < instants; i++) {
+            const int32_t* ib = base + ((size_t)t * instants + i) * 65536;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+#pragma unroll
+                for (int dr = 0; dr < 4; dr++) {
+                    const int4 a = *(const int4*)(ib + (rj + dr) * 256 + cj);
+                    acc += (unsigned)(a.x ^ a.y ^ a.z ^ a.w);
+                }
+            }
+        }
+    }
+    if (acc == 0x123456789abcdefull) sink[0] = acc;  // keep the loads alive
+}
+}  // namespace k2r
+
+extern "C" int dcdf_calib_read(const void* tiles_device, uint32_t n_tiles, uint32_t instants) {
+    using namespace k2r;
+    Runtime& rt = Runtime::get();
+    if (!rt.ok) return DCDF_ERR_NO_DEVICE;
+    if (!tiles_device || n_tiles == 0 || instants == 0) return DCDF_ERR_BAD_ARG;
+    DevBuf sink;
+    K2R_HIP(sink.alloc(8));
+    hipLaunchKernelGGL(k_calib_read, dim3(rt.cus), dim3(1024), 0, 0, (const int32_t*)tiles_device, n_tiles, instants,
+                       sink.as<unsigned long long>());
+    K2R_HIP(hipGetLastError());
+    K2R_HIP(hipDeviceSynchronize());
+    return DCDF_OK;
+}

@@ -150,6 +150,10 @@ int dcdf_suggest_fraction(const dcdf_tile_desc* tile, int mem, int32_t* out_roun
 int dcdf_synth_fill(void* dst_device, int32_t dtype, uint64_t seed, int64_t t0, int64_t t1, int64_t r0, int64_t r1,
                     int64_t c0, int64_t c1, const int32_t* costab_host);
 
+/* Profiling utility: reads n_tiles dense [instants,256,256] int32 tiles (DEVICE memory) once with the encoder's
+ * load pattern, so rocprofv3's FETCH_SIZE can be calibrated against a known byte count (MI355X_MICROARCH.md). */
+int dcdf_calib_read(const void* tiles_device, uint32_t n_tiles, uint32_t instants);
+
 const char* dcdf_strerror(int code);
 /* "gfx950 <device name>, <CUs> CUs" or NULL when no device. */
 const char* dcdf_device_name(void);
