@@ -138,9 +138,13 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
     K2R_HIP(e->d_minmax.alloc(mm_total * 8));
     K2R_HIP(e->d_args.alloc(n * sizeof(TileArgs)));
     K2R_HIP(e->d_results.alloc(n * sizeof(TileResult)));
+    // diagnostic knob (A/B runs): cap the LDS words the log stash may use; 1 = always take the re-reading passes
+    uint32_t stash_words = 0;
+    if (const char* sw = std::getenv("K2R_STASH_WORDS")) stash_words = (uint32_t)std::atoi(sw);
     for (size_t i = 0; i < n; i++) {
         const dcdf_tile_desc& t = tiles[i];
         TileArgs a{};
+        a.stash_words = stash_words;
         a.base = t.base;
         a.st = t.stride_t; a.sr = t.stride_r; a.sc = t.stride_c;
         a.instants = t.instants; a.rows = t.rows; a.cols = t.cols;

@@ -50,13 +50,15 @@ struct TileArgs {  // one Chunk::build input (device-visible copy of dcdf_tile_d
     uint8_t* out;      // output slot
     uint64_t out_cap;  // bytes
     int64_t* minmax;   // [instants][2] or null
+    uint32_t stash_words;  // 0 = default; else caps the LDS words the log stash may use (k2r_encode.h; tests, A/B runs)
+    uint32_t _pad;
 };
 
 struct TileResult {
     int32_t status;
     uint32_t snapshots;
     uint32_t logs;
-    uint32_t _pad;
+    uint32_t stash_logs;  // diagnostic: logs emitted from the LDS stash (no re-read of the input)
     uint64_t len;
     uint32_t dbg[6];  // guard record when status == ST_INTERNAL: count, code, instant, tid, value, limit
     uint32_t _pad2[2];

@@ -56,18 +56,33 @@ struct EncShared {
     int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
     uint32_t eq[C::NTOP];
     uint32_t bmT[C::WT + 1], bmE[C::WT + 1];
-    uint32_t bmV[2][C::WV + 1];
+    uint32_t bmV0[C::WV + 1];
     uint32_t bmM[2][C::WT + 1];
-    uint32_t prefV[C::WV + 2], prefM[C::WT + 2];
+    uint32_t prefM[C::WT + 2];
     uint64_t wsum[C::NW][MAX_SCAN_FIELDS];
     uint64_t tot[MAX_SCAN_FIELDS];
-    // emission work lists, in level order: internal height-2 nodes (key = blk<<2|j, plus the number of internal
-    // quads before the item) and internal quads (key = blk<<4|j<<2|qq)
-    uint32_t L2[4 * C::NBLK];
-    uint16_t L1[16 * C::NBLK];
+    // One pool of LDS words with three lives per instant:
+    //  (1) phase 1 .. plane-0 emission of a Log: the STASH.  While the cells of a block are in registers, phase 1
+    //      records everything the emission of the log candidate will need below height 2 -- one 5-word I record per
+    //      internal height-2 node (growing up from word 0) and one 3-word Q record per internal quad (growing down
+    //      from word POOLW) -- so that emitting a Log touches no input memory at all.
+    //  (2) plane-0 emission of a Snapshot, or of a Log whose stash overflowed / whose values do not fit 16 bits:
+    //      the work lists L2 (internal height-2 nodes) and L1 (internal quads) of the re-reading passes.
+    //  (3) Dac finishing: the second continuation bitmap and the per-word rank prefixes of the Lmax Dac.
+    static constexpr int POOL_L1 = 4 * C::NBLK;                 // word offset of L1 (16*NBLK u16 = 8*NBLK words)
+    static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
+    static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
+    static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? 5120 : 0);
+    uint32_t pool[POOLW];
+    K2R_HD uint32_t* L2() { return pool; }                                  // key = blk<<2|j | (quads before) << 12
+    K2R_HD uint16_t* L1() { return (uint16_t*)(pool + POOL_L1); }           // key = blk<<4|j<<2|qq
+    K2R_HD uint32_t* bmV1() { return pool + POOL_BMV1; }
+    K2R_HD uint32_t* prefV() { return pool + POOL_PREFV; }
+    uint32_t pfx[C::NBLK];  // per-thread exclusive prefix of the winner's lo pack (I1 | I2 << 16), for stash emission
     uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
     uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
     uint32_t nlistV, nlistM;
+    uint32_t stI, stQ;  // stash record counters
     int32_t err;
     uint32_t work;
     uint32_t fault[6];  // [0] = count, [1..5] = first record (code, instant, tid, value, limit)
@@ -571,13 +586,13 @@ K2R_HD void gstore8(uint8_t* p, uint8_t v) {
     *p = v;
 #endif
 }
-// WHICH = 0: Lmax Dac (sh.bmV[0], sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
+// WHICH = 0: Lmax Dac (sh.bmV0, sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
 template <int WHICH, class EX>
 K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid) {
     pos = guard_pos(ex, pos, 1, d.n0, d.code);
     gstore8(d.plane0 + pos, (uint8_t)zz);
     if (zz > 0xffu) {
-        bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV[0], pos);
+        bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV0, pos);
         const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
         d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
     }
@@ -602,7 +617,7 @@ K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t 
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (z[i] > 0xffu) {
-                bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV[0], pos + i);
+                bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV0, pos + i);
                 const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
                 d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)(pos + i) << 32) | (uint64_t)(z[i] >> 8);
             }
@@ -660,7 +675,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     constexpr int H = C::H;
     constexpr int NT = C::NT;
     auto& sh = ex.sh;
+    using SH = EncShared<C>;
     static_assert(!(PADDED && VEC), "vector loads need an unpadded tile");
+    // words of the LDS pool the stash may use (ta.stash_words: 0 = all of it; tests shrink it to force the fallback)
+    const uint32_t stash_cap = (ta.stash_words != 0 && ta.stash_words < (uint32_t)SH::POOLW) ? ta.stash_words : (uint32_t)SH::POOLW;
 
     uint8_t* const out = ta.out;
     const uint64_t cap = ta.out_cap;
@@ -692,12 +710,14 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     uint32_t blk_hdr = 6;        // where the open block's n_instants byte goes (block.rs:89)
     uint32_t blk_count = 0;      // instants in the open block
     uint32_t s_idx = 0;          // instant of the open block's snapshot (chunk.rs:52)
-    uint32_t n_snap = 0, n_log = 0;
+    uint32_t n_snap = 0, n_log = 0, n_stash = 0;
     int32_t status = ST_OK;
 
     ex.par([&](int tid, EncRegs&) {
         if (tid == 0) {
             sh.err = 0;
+            sh.stI = 0;
+            sh.stQ = 0;
             for (int i = 0; i < 6; i++) sh.fault[i] = 0;
             for (int i = 0; i < 12; i++) sh.prof[i] = 0;
             if (cap >= 6) {
@@ -759,6 +779,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     int32_t smn1[4], smx1[4], df1[4];
                     bool eq1[4];
                     Cls pend1;  // classes of the four height-1 Lmax values, valid iff P2L
+                    uint32_t recw[4], tb1 = 0, erun = 0, elen = 0;  // the I record of this node (see EncShared::pool)
+                    const uint32_t pre1 = lI1;
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
@@ -773,12 +795,29 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         eq1[qq] = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];  // log.rs:780,805
                         df1[qq] = d[0];
                         const bool P1L = !inv1[qq] && mn1[qq] != mx1[qq] && !eq1[qq];  // log.rs:137-152
+                        const int32_t vx1 = inv1[qq] ? 0 : mx1[qq] - smx1[qq];          // log.rs:133
+                        const int32_t vn1 = mn1[qq] - smn1[qq];                          // log.rs:148
+                        recw[qq] = ((uint32_t)vx1 & 0xffffu) | ((uint32_t)vn1 << 16);
+                        tb1 = (tb1 << 1) | (P1L ? 1u : 0u);
+                        if (!P1L) {  // T = 0: one eqB bit, set iff "equal" rather than uniform (log.rs:137-144)
+                            erun = (erun << 1) | ((inv1[qq] || mn1[qq] == mx1[qq]) ? 0u : 1u);
+                            elen++;
+                        }
+                        if (P1L) {  // Q record: owner, ordinal among the owner's internal quads, the four cell diffs
+                            const uint32_t m = ex.lds_add(&sh.stQ, 1u);
+                            if (3u * (m + 1u) <= stash_cap) {
+                                uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
+                                q[0] = (uint32_t)tid | (lI1 << 10);
+                                q[1] = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16);
+                                q[2] = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
+                            }
+                        }
                         lI1 += P1L ? 1u : 0u;
                         cntbits += (P1L ? 1u : 0u) << (16 + 3 * j);  // bits 16..27: internal quads per j, log
 #pragma unroll
                         for (int i = 0; i < 4; i++) lMax.add1(d[i], P1L);            // cells: t - s
-                        pend1.add1(inv1[qq] ? 0 : mx1[qq] - smx1[qq], true);          // log.rs:133
-                        lMin.add1(mn1[qq] - smn1[qq], P1L);                           // log.rs:148
+                        pend1.add1(vx1, true);
+                        lMin.add1(vn1, P1L);
                     }
                     const int32_t smn2 = min4(smn1[0], smn1[1], smn1[2], smn1[3]);
                     const int32_t smx2 = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
@@ -786,6 +825,17 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                                      df1[0] == df1[3];
                     df2[j] = df1[0];
                     const bool P2L = !inv2 && mn2 != mx2 && !eq2;
+                    if (P2L) {  // I record: owner, ordinals, T / eqB runs and the Lmax|Lmin pairs of the four quads
+                        const uint32_t k = ex.lds_add(&sh.stI, 1u);
+                        if (5u * (k + 1u) <= stash_cap) {
+                            uint32_t* p = sh.pool + 5u * k;
+                            p[0] = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (tb1 << 16) | (erun << 20) | (elen << 24);
+                            p[1] = recw[0];
+                            p[2] = recw[1];
+                            p[3] = recw[2];
+                            p[4] = recw[3];
+                        }
+                    }
                     lI2 += P2L ? 1u : 0u;
                     lMax.add(pend1, P2L);
                     lPend2.add1(inv2 ? 0 : mx2 - smx2, true);
@@ -830,6 +880,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             if (err != 0) ex.lds_min(&sh.err, err);
         });
         const int32_t perr = ex.uni(sh.err);
+        const uint32_t stI = ex.uni(sh.stI), stQ = ex.uni(sh.stQ);  // (zeroed again in phase 3)
         if (perr != 0) {
             status = perr == ERR_RANGE ? (int32_t)ST_UNSUPPORTED : perr;
             break;
@@ -932,6 +983,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 }
             };
             node(3, (uint32_t)tid);
+            if (tid == 0) {
+                sh.stI = 0;
+                sh.stQ = 0;
+            }
             if (tid < C::NTOPX) {
                 int h;
                 uint32_t j;
@@ -1040,12 +1095,14 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         TS.from(ex.uni(sh.tot[0]), tot1 & 0x3fffffffull);
         DacLayout LV{}, LM{};
         uint32_t log_size = 0, log_eq_off = 0;
+        bool log_narrow = false;  // every log value below height 3 fits 16 bits (what the stash stores)
         const bool cap254 = have_s && (blk_count - 1 == 254);  // chunk.rs:62 (checked first)
         if (have_s) {
             const uint64_t tot3 = ex.uni(sh.tot[3]);
             TL.from(ex.uni(sh.tot[2]), tot3 & 0x3fffffffull);
             uint64_t lx = (tot1 >> 30) & 0x3ffff, ln = tot1 >> 48;  // only "> 1 byte" counts are kept inline
-            if ((tot3 >> 40) != 0) {  // some log value may need 3+ bytes: count exactly
+            log_narrow = (tot3 >> 40) == 0;
+            if (!log_narrow) {  // some log value may need 3+ bytes: count exactly
                 classes_pass(1);
                 lx = ex.uni(sh.tot[4]);
                 ln = ex.uni(sh.tot[5]);
@@ -1098,6 +1155,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             break;
         }
         uint8_t* const io = out + off;  // first byte of this Snapshot / Log
+        // A Log is emitted from the stash when phase 1 managed to record all of it (else: the re-reading passes)
+        const bool use_stash = !as_snapshot && log_narrow && 5u * stI + 3u * stQ <= stash_cap && stI == TL.Ni[2] &&
+                               stQ == TL.Ni[1];
+        n_stash += use_stash ? 1u : 0u;
         const Totals<C> TT = as_snapshot ? TS : TL;
         const DacLayout DV = as_snapshot ? SV : LV;
         const DacLayout DM = as_snapshot ? SM : LM;
@@ -1115,9 +1176,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.bmT[w] = 0;
                 sh.bmE[w] = 0;
             }
-            for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV[0][w] = 0;
+            for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV0[w] = 0;
             for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
             r.pf_lo = r.sc[0];
+            sh.pfx[tid] = (uint32_t)(r.sc[0] & 0x3fffffffull);
             if (tid == 0) {
 #pragma unroll
                 for (int h = 0; h <= H; h++) {
@@ -1142,7 +1204,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         });
 
         ex.stamp(4);  // sizes, heuristic, clears, header
-        const DacSink sinkV{io + DV.by_off[0], sh.bmV[0], listV, &sh.nlistV, DV.n[0], DV.n[1], inst, kGuardVPos};
+        const DacSink sinkV{io + DV.by_off[0], sh.bmV0, listV, &sh.nlistV, DV.n[0], DV.n[1], inst, kGuardVPos};
         const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, kGuardMPos};
 
         // 5b. plane 0 of both Dacs, T (and eqB) bits
@@ -1217,7 +1279,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 for (int j = 0; j < 4; j++) {
                     if (P2[j]) {
                         emit_val<1>(ex, sinkM, TT.offI[2] + E2 + n2, zm2[j], tid);
-                        sh.L2[guard_pos(ex, E2 + n2, 1, 4 * C::NBLK, kGuardList2)] = ((uint32_t)tid << 2) | (uint32_t)j | (pre << 12);
+                        if (!use_stash)
+                            sh.L2()[guard_pos(ex, E2 + n2, 1, 4 * C::NBLK, kGuardList2)] = ((uint32_t)tid << 2) | (uint32_t)j | (pre << 12);
                         n2++;
                         pre += (r.flags >> (cshift + 3 * j)) & 7u;
                     }
@@ -1227,113 +1290,157 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         });
 
         ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
-        // 5b'. one work item per internal height-2 node (dense, level order): its four height-1 children
         const uint32_t nI2 = TT.Ni[2], nI1 = TT.Ni[1];
-        ex.par([&](int tid, EncRegs&) {
-            int32_t lerr = 0;  // loads were validated in phase 1
-            for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
-                const uint32_t ent = sh.L2[k];
-                const uint32_t blk = (ent >> 2) & (C::NBLK - 1), j = ent & 3u, pre = ent >> 12;
-                uint32_t r0, c0;
-                blk_origin((int)blk, r0, c0);
-                const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-                int32_t t16[16];
-                load_sub16<PADDED, VEC>(ta, inst, r0, c0, (int)j, t16, lerr);
-                int32_t mn1[4], mx1[4];
-                bool inv1[4];
+        if (use_stash) {
+            // 5b'. (Log, from the stash) one work item per I record: the four height-1 children of an internal
+            // height-2 node.  Records are in arrival order; their place in level order comes from the owner's prefix.
+            ex.par([&](int tid, EncRegs&) {
+                for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
+                    const uint32_t* rec = sh.pool + 5u * k;
+                    const uint32_t hdr = rec[0];
+                    const uint32_t pf = sh.pfx[hdr & 1023u];
+                    const uint32_t kk = ((pf >> 16) & 0x3fffu) + ((hdr >> 10) & 3u);  // rank among internal height-2 nodes
+                    const uint32_t pre = (pf & 0xffffu) + ((hdr >> 12) & 15u);        // internal quads before this node
+                    const uint32_t tb1 = (hdr >> 16) & 15u, erun = (hdr >> 20) & 15u, elen = (hdr >> 24) & 7u;
+                    uint32_t w[4];
 #pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    mn1[qq] = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                    mx1[qq] = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
-                    inv1[qq] = inval(rj + 2 * (qq >> 1), cj + 2 * (qq & 1));
-                }
-                uint32_t z1v[4], zm1[4], tb1 = 0, erun = 0, elen = 0;
-                bool P1[4];
-                if (as_snapshot) {
-                    const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
-                    const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
+                    for (int qq = 0; qq < 4; qq++) w[qq] = rec[1 + qq];
+                    const uint32_t p1 = TT.offV[1] + 4 * kk;
+                    emit4<0>(ex, sinkV, p1, zz32((int32_t)(int16_t)(w[0] & 0xffffu)), zz32((int32_t)(int16_t)(w[1] & 0xffffu)),
+                             zz32((int32_t)(int16_t)(w[2] & 0xffffu)), zz32((int32_t)(int16_t)(w[3] & 0xffffu)), tid);
+                    bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
+                    bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * kk - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
+                    uint32_t n1 = 0;
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
-                        P1[qq] = !inv1[qq] && mn1[qq] != mx1[qq];
-                        z1v[qq] = zz32(inv1[qq] ? mx2 : mx2 - mx1[qq]);
-                        zm1[qq] = zz32(mn1[qq] - mn2);
-                        tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
-                    }
-                } else {
-                    int32_t s16[16];
-                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, (int)j, s16, lerr);  // L2 / Infinity Cache hit
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq++) {
-                        const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
-                        int32_t d[4];
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
-                        const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                        const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
-                        const bool eq1 = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
-                        const bool unif1 = inv1[qq] || mn1[qq] == mx1[qq];
-                        P1[qq] = !unif1 && !eq1;
-                        z1v[qq] = zz32(inv1[qq] ? 0 : mx1[qq] - smx1);
-                        zm1[qq] = zz32(mn1[qq] - smn1);
-                        tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
-                        if (!P1[qq]) {
-                            erun = (erun << 1) | (unif1 ? 0u : 1u);
-                            elen++;
+                        if ((tb1 >> (3 - qq)) & 1u) {
+                            emit_val<1>(ex, sinkM, TT.offI[1] + pre + n1, zz32((int32_t)w[qq] >> 16), tid);
+                            n1++;
                         }
                     }
                 }
-                const uint32_t p1 = TT.offV[1] + 4 * k;  // level order: four children per internal parent
-                emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
-                bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
-                if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * k - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
-                uint32_t n1 = 0;
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    if (P1[qq]) {
-                        emit_val<1>(ex, sinkM, TT.offI[1] + pre + n1, zm1[qq], tid);
-                        sh.L1[guard_pos(ex, pre + n1, 1, 16 * C::NBLK, kGuardList1)] = (uint16_t)((blk << 4) | (j << 2) | (uint32_t)qq);
-                        n1++;
+                guard_flush(ex);
+            });
+            ex.stamp(11);
+            // 5b''. one work item per Q record: the four cells of an internal quad
+            ex.par([&](int tid, EncRegs&) {
+                for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
+                    const uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
+                    const uint32_t hdr = q[0], a = q[1], b = q[2];
+                    const uint32_t pos = (sh.pfx[hdr & 1023u] & 0xffffu) + ((hdr >> 10) & 15u);  // rank among internal quads
+                    emit4<0>(ex, sinkV, TT.offV[0] + 4 * pos, zz32((int32_t)(int16_t)(a & 0xffffu)), zz32((int32_t)a >> 16),
+                             zz32((int32_t)(int16_t)(b & 0xffffu)), zz32((int32_t)b >> 16), tid);
+                }
+                guard_flush(ex);
+            });
+        } else {
+            // 5b'. one work item per internal height-2 node (dense, level order): its four height-1 children
+            ex.par([&](int tid, EncRegs&) {
+                int32_t lerr = 0;  // loads were validated in phase 1
+                for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
+                    const uint32_t ent = sh.L2()[k];
+                    const uint32_t blk = (ent >> 2) & (C::NBLK - 1), j = ent & 3u, pre = ent >> 12;
+                    uint32_t r0, c0;
+                    blk_origin((int)blk, r0, c0);
+                    const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
+                    int32_t t16[16];
+                    load_sub16<PADDED, VEC>(ta, inst, r0, c0, (int)j, t16, lerr);
+                    int32_t mn1[4], mx1[4];
+                    bool inv1[4];
+    #pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        mn1[qq] = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                        mx1[qq] = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
+                        inv1[qq] = inval(rj + 2 * (qq >> 1), cj + 2 * (qq & 1));
+                    }
+                    uint32_t z1v[4], zm1[4], tb1 = 0, erun = 0, elen = 0;
+                    bool P1[4];
+                    if (as_snapshot) {
+                        const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
+                        const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
+    #pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            P1[qq] = !inv1[qq] && mn1[qq] != mx1[qq];
+                            z1v[qq] = zz32(inv1[qq] ? mx2 : mx2 - mx1[qq]);
+                            zm1[qq] = zz32(mn1[qq] - mn2);
+                            tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
+                        }
+                    } else {
+                        int32_t s16[16];
+                        load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, (int)j, s16, lerr);  // L2 / Infinity Cache hit
+    #pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
+                            int32_t d[4];
+    #pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
+                            const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                            const int32_t smx1 = max4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
+                            const bool eq1 = d[0] == d[1] && d[0] == d[2] && d[0] == d[3];
+                            const bool unif1 = inv1[qq] || mn1[qq] == mx1[qq];
+                            P1[qq] = !unif1 && !eq1;
+                            z1v[qq] = zz32(inv1[qq] ? 0 : mx1[qq] - smx1);
+                            zm1[qq] = zz32(mn1[qq] - smn1);
+                            tb1 = (tb1 << 1) | (P1[qq] ? 1u : 0u);
+                            if (!P1[qq]) {
+                                erun = (erun << 1) | (unif1 ? 0u : 1u);
+                                elen++;
+                            }
+                        }
+                    }
+                    const uint32_t p1 = TT.offV[1] + 4 * k;  // level order: four children per internal parent
+                    emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
+                    bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
+                    if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * k - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
+                    uint32_t n1 = 0;
+    #pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        if (P1[qq]) {
+                            emit_val<1>(ex, sinkM, TT.offI[1] + pre + n1, zm1[qq], tid);
+                            sh.L1()[guard_pos(ex, pre + n1, 1, 16 * C::NBLK, kGuardList1)] = (uint16_t)((blk << 4) | (j << 2) | (uint32_t)qq);
+                            n1++;
+                        }
                     }
                 }
-            }
-            guard_flush(ex);
-        });
+                guard_flush(ex);
+            });
 
-        ex.stamp(11);  // emission pass B (height-1 groups)
-        // 5b''. one work item per internal quad: its four cells
-        ex.par([&](int tid, EncRegs&) {
-            int32_t lerr = 0;
-            for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
-                const uint32_t key = sh.L1[m];
-                const uint32_t blk = key >> 4, j = (key >> 2) & 3u, qq = key & 3u;
-                uint32_t r0, c0;
-                blk_origin((int)blk, r0, c0);
-                const uint32_t rq = r0 + 4 * (j >> 1) + 2 * (qq >> 1), cq = c0 + 4 * (j & 1) + 2 * (qq & 1);
-                int32_t t4[4];
-                load_quad<PADDED, VEC>(ta, inst, rq, cq, t4, lerr);
-                uint32_t z[4];
-                if (as_snapshot) {
-                    const int32_t mx1 = max4(t4[0], t4[1], t4[2], t4[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? mx1 : mx1 - t4[i]);
-                } else {
-                    int32_t s4[4];
-                    load_quad<PADDED, VEC>(ta, s_idx, rq, cq, s4, lerr);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t4[i] - s4[i]);
+            ex.stamp(11);  // emission pass B (height-1 groups)
+            // 5b''. one work item per internal quad: its four cells
+            ex.par([&](int tid, EncRegs&) {
+                int32_t lerr = 0;
+                for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
+                    const uint32_t key = sh.L1()[m];
+                    const uint32_t blk = key >> 4, j = (key >> 2) & 3u, qq = key & 3u;
+                    uint32_t r0, c0;
+                    blk_origin((int)blk, r0, c0);
+                    const uint32_t rq = r0 + 4 * (j >> 1) + 2 * (qq >> 1), cq = c0 + 4 * (j & 1) + 2 * (qq & 1);
+                    int32_t t4[4];
+                    load_quad<PADDED, VEC>(ta, inst, rq, cq, t4, lerr);
+                    uint32_t z[4];
+                    if (as_snapshot) {
+                        const int32_t mx1 = max4(t4[0], t4[1], t4[2], t4[3]);
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? mx1 : mx1 - t4[i]);
+                    } else {
+                        int32_t s4[4];
+                        load_quad<PADDED, VEC>(ta, s_idx, rq, cq, s4, lerr);
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t4[i] - s4[i]);
+                    }
+                    emit4<0>(ex, sinkV, TT.offV[0] + 4 * m, z[0], z[1], z[2], z[3], tid);
                 }
-                emit4<0>(ex, sinkV, TT.offV[0] + 4 * m, z[0], z[1], z[2], z[3], tid);
-            }
-            guard_flush(ex);
-        });
+                guard_flush(ex);
+            });
 
+        }
         ex.stamp(as_snapshot ? 5 : 6);  // plane-0 emission (5: snapshot, 6: log)
         // 5c. bitmaps + higher planes
         bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
         if (!as_snapshot) bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
         ex.stamp(7);  // T / eqB bitmaps
-        dac_finish<C>(ex, DV, io, sh.bmV[0], sh.bmV[1], sh.prefV, listV, &sh.nlistV);
+        dac_finish<C>(ex, DV, io, sh.bmV0, sh.bmV1(), sh.prefV(), listV, &sh.nlistV);
         ex.stamp(8);  // Lmax Dac: bitmaps + planes >= 1
         dac_finish<C>(ex, DM, io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
         ex.stamp(9);  // Lmin Dac: planes >= 1
@@ -1353,6 +1460,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             res->status = faulted ? (int32_t)ST_INTERNAL : status;
             res->snapshots = n_snap;
             res->logs = n_log;
+            res->stash_logs = n_stash;
             res->len = (status == ST_OK && !faulted) ? off : 0;
             for (int i = 0; i < 6; i++) res->dbg[i] = sh.fault[i];
             for (int i = 0; i < 12; i++) res->prof[i] = sh.prof[i];

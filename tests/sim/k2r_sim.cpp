@@ -29,6 +29,9 @@ static void run_l(const TileArgs& ta, TileResult* res, bool padded, bool vec) {
     else run<LOG2S, false, false>(ta, res);
 }
 
+static uint32_t g_last_stash_logs = 0;
+extern "C" uint32_t sim_last_stash_logs() { return g_last_stash_logs; }
+
 extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, int64_t sc, uint32_t instants,
                           uint32_t rows, uint32_t cols, int fbits, int round, uint8_t* out, uint64_t cap,
                           int64_t* minmax, int force_novec, int32_t* status, uint32_t* snapshots, uint32_t* logs,
@@ -38,6 +41,7 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
     ta.instants = instants; ta.rows = rows; ta.cols = cols;
     ta.dtype = dtype; ta.fbits = (dtype == ENC_F32 || dtype == ENC_F64) ? (uint32_t)fbits : 0; ta.round = (uint32_t)round;
     ta.out = out; ta.out_cap = cap; ta.minmax = minmax;
+    if (const char* sw = std::getenv("K2R_SIM_STASH_WORDS")) ta.stash_words = (uint32_t)std::atoi(sw);  // force the fallback passes
     uint32_t m = rows > cols ? rows : cols;
     int lg = 0;
     while ((1u << lg) < m) lg++;
@@ -55,6 +59,7 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
         case 7: run_l<7>(ta, &res, padded, vec); break;
         case 8: run_l<8>(ta, &res, padded, vec); break;
     }
+    g_last_stash_logs = res.stash_logs;
     *status = res.status; *snapshots = res.snapshots; *logs = res.logs; *len = res.len;
     return 0;
 }

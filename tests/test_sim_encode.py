@@ -149,3 +149,40 @@ def test_output_capacity_reported():
     assert S.encode(a, cap=len(ref) - 1)[0] == -100
     st, data, _, _ = S.encode(a, cap=len(ref))
     assert st == 0 and data == ref
+
+
+def _stash_logs():
+    S.lib().sim_last_stash_logs.restype = __import__("ctypes").c_uint32
+    return S.lib().sim_last_stash_logs()
+
+
+def test_log_stash_used_and_fallback(monkeypatch):
+    """Logs are normally emitted from the LDS stash built in phase 1; when the stash cannot hold an instant (forced
+    here by shrinking it) or a value does not fit 16 bits, the re-reading passes produce the same bytes."""
+    a = synth.cells(0xDCDF0002, 0, 5, 0, 256, 0, 256, np.int32)
+    data, _ = check(a)
+    _, _, ns, nl = S.encode(a)
+    assert nl > 0 and _stash_logs() == nl  # every log came from the stash
+    for words in ("1", "4000", "9000"):
+        monkeypatch.setenv("K2R_SIM_STASH_WORDS", words)
+        data2, _ = check(a)
+        assert data2 == data
+        assert _stash_logs() < nl
+    monkeypatch.delenv("K2R_SIM_STASH_WORDS")
+    # log differences beyond 16 bits (but a log still wins): not stashable -> fallback
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 50, size=(64, 64))
+    b = np.stack([base, base, base]).astype(np.int64)
+    b[1, 5, 7] += 100000
+    b[2, 9, 9] -= 70000
+    b[2, 40:44, 40:44] += rng.integers(-40000, 40000, size=(4, 4))
+    check(b)
+    _, _, ns, nl = S.encode(b)
+    assert nl == 2 and _stash_logs() == 0
+    # ...and the same shape with small differences does use it
+    c = np.stack([base, base, base]).astype(np.int64)
+    c[1, 5, 7] += 1000
+    c[2, 40:44, 40:44] += rng.integers(-400, 400, size=(4, 4))
+    check(c)
+    _, _, ns, nl = S.encode(c)
+    assert nl == 2 and _stash_logs() == 2
