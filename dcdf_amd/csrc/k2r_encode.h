@@ -68,16 +68,15 @@ struct EncShared {
     //      from word POOLW) -- so that emitting a Log touches no input memory at all.
     //  (2) plane-0 emission of a Snapshot, or of a Log whose stash overflowed / whose values do not fit 16 bits:
     //      the work lists L2 (internal height-2 nodes) and L1 (internal quads) of the re-reading passes.
-    //  (3) Dac finishing: the second continuation bitmap and the per-word rank prefixes of the Lmax Dac.
+    //  (3) Dac finishing in list mode: the second continuation bitmap of the Lmax Dac.
     static constexpr int POOL_L1 = 4 * C::NBLK;                 // word offset of L1 (16*NBLK u16 = 8*NBLK words)
     static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
-    static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
-    static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? 5120 : 0);
+    static constexpr int POOLW = POOL_BMV1 + C::WV + 1 + (C::H == 8 ? 7280 : 0);  // sidelen 256: LDS filled to 160 KB
     uint32_t pool[POOLW];
     K2R_HD uint32_t* L2() { return pool; }                                  // key = blk<<2|j | (quads before) << 12
     K2R_HD uint16_t* L1() { return (uint16_t*)(pool + POOL_L1); }           // key = blk<<4|j<<2|qq
     K2R_HD uint32_t* bmV1() { return pool + POOL_BMV1; }
-    K2R_HD uint32_t* prefV() { return pool + POOL_PREFV; }
+    uint32_t prefV[C::WV + 2];  // per-word rank prefixes of the Lmax Dac's continuation bitmap
     uint32_t pfx[C::NBLK];  // per-thread exclusive prefix of the winner's lo pack (I1 | I2 << 16), for stash emission
     uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
     uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
@@ -479,6 +478,8 @@ K2R_HD uint32_t bm_rank(const uint32_t* bm, const uint32_t* pref, uint32_t p) {
     return r;
 }
 
+K2R_HD void gstore32u(uint8_t* p, uint32_t v);
+K2R_HD void gstore8(uint8_t* p, uint8_t v);
 // Computes per-word exclusive popcount prefixes of an LDS bitmap (pref[0..W], pref[W] = total) and
 // writes the serialized BitMap (bitmap.rs:128-138) to `dst`.
 template <class C, class EX>
@@ -505,12 +506,12 @@ K2R_HD void bitmap_finish_write(EX& ex, const uint32_t* bm, uint32_t nbits, uint
     ex.par([&](int tid, EncRegs&) {
         const uint32_t nidx = nbits / 128;  // bitmap.rs:70
         if (tid == 0) {
-            store_be32(dst, nbits);
-            store_be32(dst + 4, 4u);  // k, bitmap.rs:69,130
+            gstore32u(dst, __builtin_bswap32(nbits));
+            gstore32u(dst + 4, __builtin_bswap32(4u));  // k, bitmap.rs:69,130
         }
-        for (uint32_t b = (uint32_t)tid; b < nidx; b += NT) store_be32(dst + 8 + 4 * b, pref[4 * (b + 1)]);
+        for (uint32_t b = (uint32_t)tid; b < nidx; b += NT) gstore32u(dst + 8 + 4 * b, __builtin_bswap32(pref[4 * (b + 1)]));
         uint8_t* wd = dst + 8 + 4 * nidx;
-        for (uint32_t w = (uint32_t)tid; w < W; w += NT) store_be32(wd + 4 * w, bm[w]);
+        for (uint32_t w = (uint32_t)tid; w < W; w += NT) gstore32u(wd + 4 * w, __builtin_bswap32(bm[w]));
     });
 }
 
@@ -576,7 +577,22 @@ struct DacSink {
     uint32_t n1;       // number of values with more than one byte (list entries are < n1)
     uint32_t inst;     // for diagnostics
     uint32_t code;     // guard code base
+    uint8_t* plane1;         // two-pass mode: where byte 1 of the r-th long value goes
+    const uint32_t* pref;    // two-pass mode: per-word rank prefixes of bm0
 };
+// Emission modes.
+//   EM_LIST : one pass; plane-0 bytes are stored, values longer than a byte are appended to the overflow list and
+//             placed by dac_finish (any number of planes).
+//   EM_P0 / EM_P1 : two passes over the same sources for Dacs known to have at most two planes (every value
+//             < 2^16 after zig-zag).  EM_P0 stores the plane-0 bytes and sets the continuation bits; once the
+//             bitmap's rank prefixes exist, EM_P1 revisits the sources and stores byte 1 of every long value at
+//             rank1(continuation, pos) -- the decoder's own hop (dac.rs:83-90) -- with no list and no atomics.
+enum : int { EM_LIST = 0, EM_P0 = 1, EM_P1 = 2 };
+template <int V>
+struct EmTag {
+    static constexpr int value = V;
+};
+
 // global-memory byte store (the pointers travel through structs, so the compiler would otherwise have to
 // emit flat_store_byte)
 K2R_HD void gstore8(uint8_t* p, uint8_t v) {
@@ -586,20 +602,6 @@ K2R_HD void gstore8(uint8_t* p, uint8_t v) {
     *p = v;
 #endif
 }
-// WHICH = 0: Lmax Dac (sh.bmV0, sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
-template <int WHICH, class EX>
-K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid) {
-    pos = guard_pos(ex, pos, 1, d.n0, d.code);
-    gstore8(d.plane0 + pos, (uint8_t)zz);
-    if (zz > 0xffu) {
-        bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV0, pos);
-        const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
-        d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
-    }
-}
-
-// Four values at consecutive positions pos..pos+3 (the children of one internal node are always adjacent in
-// level order): one unaligned 4-byte store of the plane-0 bytes; values longer than a byte take the slow path.
 K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -608,21 +610,75 @@ K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
     __builtin_memcpy(p, &v, 4);
 #endif
 }
-template <int WHICH, class EX>
+// WHICH = 0: Lmax Dac (sh.bmV0, sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
+template <int WHICH, int MODE = EM_LIST, class EX>
+K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid) {
+    pos = guard_pos(ex, pos, 1, d.n0, d.code);
+    uint32_t* const bm0 = WHICH ? ex.sh.bmM[0] : ex.sh.bmV0;
+    if (MODE == EM_P1) {
+        if (zz > 0xffu) {
+            const uint32_t q = guard_pos(ex, bm_rank(bm0, d.pref, pos), 1, d.n1, d.code + 1);
+            gstore8(d.plane1 + q, (uint8_t)(zz >> 8));
+        }
+        return;
+    }
+    gstore8(d.plane0 + pos, (uint8_t)zz);
+    if (zz > 0xffu) {
+        bm_set(ex, bm0, pos);
+        if (MODE == EM_LIST) {
+            const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
+            d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
+        }
+    }
+}
+
+// Four values at consecutive positions pos..pos+3 (the children of one internal node are always adjacent in
+// level order): one unaligned 4-byte store of the plane-0 bytes; values longer than a byte take the slow path.
+template <int WHICH, int MODE = EM_LIST, class EX>
 K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3, int tid) {
     pos = guard_pos(ex, pos, 4, d.n0, d.code);
+    uint32_t* const bm0 = WHICH ? ex.sh.bmM[0] : ex.sh.bmV0;
+    if (MODE == EM_P1) {
+        if ((z0 | z1 | z2 | z3) > 0xffu) {
+            uint32_t q = bm_rank(bm0, d.pref, pos);
+            const uint32_t z[4] = {z0, z1, z2, z3};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (z[i] > 0xffu) {
+                    gstore8(d.plane1 + guard_pos(ex, q, 1, d.n1, d.code + 1), (uint8_t)(z[i] >> 8));
+                    q++;
+                }
+            }
+        }
+        return;
+    }
     gstore32u(d.plane0 + pos, (z0 & 0xffu) | ((z1 & 0xffu) << 8) | ((z2 & 0xffu) << 16) | (z3 << 24));
     if ((z0 | z1 | z2 | z3) > 0xffu) {
-        const uint32_t z[4] = {z0, z1, z2, z3};
+        if (MODE == EM_P0) {
+            const uint32_t run = (z0 > 0xffu ? 8u : 0u) | (z1 > 0xffu ? 4u : 0u) | (z2 > 0xffu ? 2u : 0u) | (z3 > 0xffu ? 1u : 0u);
+            bm_or_run(ex, bm0, pos, 4, run);
+        } else {
+            const uint32_t z[4] = {z0, z1, z2, z3};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (z[i] > 0xffu) {
-                bm_set(ex, WHICH ? ex.sh.bmM[0] : ex.sh.bmV0, pos + i);
-                const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
-                d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)(pos + i) << 32) | (uint64_t)(z[i] >> 8);
+            for (int i = 0; i < 4; i++) {
+                if (z[i] > 0xffu) {
+                    bm_set(ex, bm0, pos + i);
+                    const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
+                    d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)(pos + i) << 32) | (uint64_t)(z[i] >> 8);
+                }
             }
         }
     }
+}
+
+// The BitMap of `nbits` zero bits (bitmap.rs:128-138): the last level of a Dac never continues.
+template <class C, class EX>
+K2R_HD void bitmap_write_zero(EX& ex, uint32_t nbits, uint8_t* dst) {
+    const uint32_t nw = 2u + nbits / 128u + (nbits + 31u) / 32u;  // header, rank index, words
+    ex.par_nosync([&](int tid, EncRegs&) {
+        for (uint32_t w = (uint32_t)tid; w < nw; w += C::NT)
+            gstore32u(dst + 4 * w, w == 0 ? __builtin_bswap32(nbits) : (w == 1 ? __builtin_bswap32(4u) : 0u));
+    });
 }
 
 // Planes 1..nlev-1 of one Dac from its overflow list; also writes every level's BitMap.
@@ -1204,11 +1260,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         });
 
         ex.stamp(4);  // sizes, heuristic, clears, header
-        const DacSink sinkV{io + DV.by_off[0], sh.bmV0, listV, &sh.nlistV, DV.n[0], DV.n[1], inst, kGuardVPos};
-        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, kGuardMPos};
+        const DacSink sinkV{io + DV.by_off[0], sh.bmV0, listV, &sh.nlistV, DV.n[0], DV.n[1], inst, kGuardVPos,
+                            io + DV.by_off[1], sh.prefV};
+        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, kGuardMPos,
+                            io + DM.by_off[1], sh.prefM};
 
-        // 5b. plane 0 of both Dacs, T (and eqB) bits
-        ex.par([&](int tid, EncRegs& r) {
+        // 5b. plane 0 of both Dacs, T (and eqB) bits.  Pass A covers the nodes of heights >= 2; it is instantiated
+        // per emission mode (EM_P1 repeats the walk only to place second bytes, so it skips the bitmaps and lists).
+        auto passA = [&](auto mode_tag) {
+          constexpr int MODE = decltype(mode_tag)::value;
+          ex.par([&](int tid, EncRegs& r) {
             uint32_t r0, c0;
             blk_origin(tid, r0, c0);
             const uint64_t pLo = r.pf_lo;
@@ -1224,11 +1285,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 if (h < H) vrank = 4 * bits_count(tb, tbit(h + 1, 0), tbit(h + 1, j >> 2)) + (j & 3);
                 const uint32_t idx = sh.ttV[h] + vrank;
                 const uint32_t irank = (h == 3) ? unpackI(3, pLo, 0) : bits_count(tb, tbit(h, 0), tbit(h, j));
-                emit_val<0>(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
+                emit_val<0, MODE>(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
                 if (p) {
-                    bm_set(ex, sh.bmT, guard_pos(ex, idx, 1, TT.LT, kGuardTOwn));
-                    emit_val<1>(ex, sinkM, sh.ttI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
-                } else if (!as_snapshot) {
+                    if (MODE != EM_P1) bm_set(ex, sh.bmT, guard_pos(ex, idx, 1, TT.LT, kGuardTOwn));
+                    emit_val<1, MODE>(ex, sinkM, sh.ttI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
+                } else if (!as_snapshot && MODE != EM_P1) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
                     if (e) bm_set(ex, sh.bmE, guard_pos(ex, sh.ttZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
@@ -1270,16 +1331,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                     tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
                 }
-                emit4<0>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
-                bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
-                if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
+                emit4<0, MODE>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
+                if (MODE != EM_P1) bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
+                if (!as_snapshot && MODE != EM_P1) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
                 uint32_t n2 = 0, pre = E1;
                 const uint32_t cshift = as_snapshot ? 4u : 16u;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (P2[j]) {
-                        emit_val<1>(ex, sinkM, TT.offI[2] + E2 + n2, zm2[j], tid);
-                        if (!use_stash)
+                        emit_val<1, MODE>(ex, sinkM, TT.offI[2] + E2 + n2, zm2[j], tid);
+                        if (MODE == EM_LIST)
                             sh.L2()[guard_pos(ex, E2 + n2, 1, 4 * C::NBLK, kGuardList2)] = ((uint32_t)tid << 2) | (uint32_t)j | (pre << 12);
                         n2++;
                         pre += (r.flags >> (cshift + 3 * j)) & 7u;
@@ -1288,52 +1349,84 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
             guard_flush(ex);
         });
-
-        ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
+        };
         const uint32_t nI2 = TT.Ni[2], nI1 = TT.Ni[1];
         if (use_stash) {
-            // 5b'. (Log, from the stash) one work item per I record: the four height-1 children of an internal
-            // height-2 node.  Records are in arrival order; their place in level order comes from the owner's prefix.
-            ex.par([&](int tid, EncRegs&) {
-                for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
-                    const uint32_t* rec = sh.pool + 5u * k;
-                    const uint32_t hdr = rec[0];
-                    const uint32_t pf = sh.pfx[hdr & 1023u];
-                    const uint32_t kk = ((pf >> 16) & 0x3fffu) + ((hdr >> 10) & 3u);  // rank among internal height-2 nodes
-                    const uint32_t pre = (pf & 0xffffu) + ((hdr >> 12) & 15u);        // internal quads before this node
-                    const uint32_t tb1 = (hdr >> 16) & 15u, erun = (hdr >> 20) & 15u, elen = (hdr >> 24) & 7u;
-                    uint32_t w[4];
+            // ---- a Log whose values all fit two bytes, emitted from the stash in two passes (EM_P0, EM_P1) ----
+            // one work item per I record: the four height-1 children of an internal height-2 node.  Records are in
+            // arrival order; their place in level order comes from the owner's prefix.
+            auto passI = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                ex.par([&](int tid, EncRegs&) {
+                    for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
+                        const uint32_t* rec = sh.pool + 5u * k;
+                        const uint32_t hdr = rec[0];
+                        const uint32_t pf = sh.pfx[hdr & 1023u];
+                        const uint32_t kk = ((pf >> 16) & 0x3fffu) + ((hdr >> 10) & 3u);  // rank among internal height-2 nodes
+                        const uint32_t pre = (pf & 0xffffu) + ((hdr >> 12) & 15u);        // internal quads before this node
+                        const uint32_t tb1 = (hdr >> 16) & 15u, erun = (hdr >> 20) & 15u, elen = (hdr >> 24) & 7u;
+                        uint32_t w[4];
 #pragma unroll
-                    for (int qq = 0; qq < 4; qq++) w[qq] = rec[1 + qq];
-                    const uint32_t p1 = TT.offV[1] + 4 * kk;
-                    emit4<0>(ex, sinkV, p1, zz32((int32_t)(int16_t)(w[0] & 0xffffu)), zz32((int32_t)(int16_t)(w[1] & 0xffffu)),
-                             zz32((int32_t)(int16_t)(w[2] & 0xffffu)), zz32((int32_t)(int16_t)(w[3] & 0xffffu)), tid);
-                    bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
-                    bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * kk - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
-                    uint32_t n1 = 0;
+                        for (int qq = 0; qq < 4; qq++) w[qq] = rec[1 + qq];
+                        const uint32_t p1 = TT.offV[1] + 4 * kk;
+                        emit4<0, MODE>(ex, sinkV, p1, zz32((int32_t)(int16_t)(w[0] & 0xffffu)), zz32((int32_t)(int16_t)(w[1] & 0xffffu)),
+                                       zz32((int32_t)(int16_t)(w[2] & 0xffffu)), zz32((int32_t)(int16_t)(w[3] & 0xffffu)), tid);
+                        if (MODE != EM_P1) {
+                            bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
+                            bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * kk - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
+                        }
+                        uint32_t n1 = 0;
 #pragma unroll
-                    for (int qq = 0; qq < 4; qq++) {
-                        if ((tb1 >> (3 - qq)) & 1u) {
-                            emit_val<1>(ex, sinkM, TT.offI[1] + pre + n1, zz32((int32_t)w[qq] >> 16), tid);
-                            n1++;
+                        for (int qq = 0; qq < 4; qq++) {
+                            if ((tb1 >> (3 - qq)) & 1u) {
+                                emit_val<1, MODE>(ex, sinkM, TT.offI[1] + pre + n1, zz32((int32_t)w[qq] >> 16), tid);
+                                n1++;
+                            }
                         }
                     }
-                }
-                guard_flush(ex);
-            });
+                    guard_flush(ex);
+                });
+            };
+            // one work item per Q record: the four cells of an internal quad
+            auto passQ = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                ex.par([&](int tid, EncRegs&) {
+                    for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
+                        const uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
+                        const uint32_t hdr = q[0], a = q[1], b = q[2];
+                        const uint32_t pos = (sh.pfx[hdr & 1023u] & 0xffffu) + ((hdr >> 10) & 15u);  // rank among internal quads
+                        emit4<0, MODE>(ex, sinkV, TT.offV[0] + 4 * pos, zz32((int32_t)(int16_t)(a & 0xffffu)), zz32((int32_t)a >> 16),
+                                       zz32((int32_t)(int16_t)(b & 0xffffu)), zz32((int32_t)b >> 16), tid);
+                    }
+                    guard_flush(ex);
+                });
+            };
+            using P0 = EmTag<EM_P0>;
+            using P1 = EmTag<EM_P1>;
+            passA(P0{});
+            ex.stamp(10);
+            passI(P0{});
             ex.stamp(11);
-            // 5b''. one work item per Q record: the four cells of an internal quad
-            ex.par([&](int tid, EncRegs&) {
-                for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
-                    const uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
-                    const uint32_t hdr = q[0], a = q[1], b = q[2];
-                    const uint32_t pos = (sh.pfx[hdr & 1023u] & 0xffffu) + ((hdr >> 10) & 15u);  // rank among internal quads
-                    emit4<0>(ex, sinkV, TT.offV[0] + 4 * pos, zz32((int32_t)(int16_t)(a & 0xffffu)), zz32((int32_t)a >> 16),
-                             zz32((int32_t)(int16_t)(b & 0xffffu)), zz32((int32_t)b >> 16), tid);
-                }
-                guard_flush(ex);
-            });
+            passQ(P0{});
+            ex.stamp(6);
+            bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
+            bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
+            ex.stamp(7);
+            // continuation bitmaps of both Dacs (serialized + rank prefixes), then the second bytes
+            if (DV.nlev > 0) bitmap_finish_write<C>(ex, sh.bmV0, DV.n[0], sh.prefV, io + DV.bm_off[0]);
+            if (DM.nlev > 0) bitmap_finish_write<C>(ex, sh.bmM[0], DM.n[0], sh.prefM, io + DM.bm_off[0]);
+            ex.stamp(8);
+            if (DV.nlev > 1 || DM.nlev > 1) {
+                passA(P1{});
+                passI(P1{});
+                passQ(P1{});
+                if (DV.nlev > 1) bitmap_write_zero<C>(ex, DV.n[1], io + DV.bm_off[1]);
+                if (DM.nlev > 1) bitmap_write_zero<C>(ex, DM.n[1], io + DM.bm_off[1]);
+            }
+            ex.stamp(9);
         } else {
+            passA(EmTag<EM_LIST>{});
+            ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
             // 5b'. one work item per internal height-2 node (dense, level order): its four height-1 children
             ex.par([&](int tid, EncRegs&) {
                 int32_t lerr = 0;  // loads were validated in phase 1
@@ -1347,7 +1440,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     load_sub16<PADDED, VEC>(ta, inst, r0, c0, (int)j, t16, lerr);
                     int32_t mn1[4], mx1[4];
                     bool inv1[4];
-    #pragma unroll
+#pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         mn1[qq] = min4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
                         mx1[qq] = max4(t16[4 * qq], t16[4 * qq + 1], t16[4 * qq + 2], t16[4 * qq + 3]);
@@ -1358,7 +1451,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     if (as_snapshot) {
                         const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
                         const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
-    #pragma unroll
+#pragma unroll
                         for (int qq = 0; qq < 4; qq++) {
                             P1[qq] = !inv1[qq] && mn1[qq] != mx1[qq];
                             z1v[qq] = zz32(inv1[qq] ? mx2 : mx2 - mx1[qq]);
@@ -1368,11 +1461,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     } else {
                         int32_t s16[16];
                         load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, (int)j, s16, lerr);  // L2 / Infinity Cache hit
-    #pragma unroll
+#pragma unroll
                         for (int qq = 0; qq < 4; qq++) {
                             const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
                             int32_t d[4];
-    #pragma unroll
+#pragma unroll
                             for (int i = 0; i < 4; i++)
                                 d[i] = inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t16[4 * qq + i] - s16[4 * qq + i];
                             const int32_t smn1 = min4(s16[4 * qq], s16[4 * qq + 1], s16[4 * qq + 2], s16[4 * qq + 3]);
@@ -1394,7 +1487,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
                     if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * k - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
                     uint32_t n1 = 0;
-    #pragma unroll
+#pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         if (P1[qq]) {
                             emit_val<1>(ex, sinkM, TT.offI[1] + pre + n1, zm1[qq], tid);
@@ -1421,29 +1514,28 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     uint32_t z[4];
                     if (as_snapshot) {
                         const int32_t mx1 = max4(t4[0], t4[1], t4[2], t4[3]);
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? mx1 : mx1 - t4[i]);
                     } else {
                         int32_t s4[4];
                         load_quad<PADDED, VEC>(ta, s_idx, rq, cq, s4, lerr);
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < 4; i++) z[i] = zz32(inval(rq + (i >> 1), cq + (i & 1)) ? 0 : t4[i] - s4[i]);
                     }
                     emit4<0>(ex, sinkV, TT.offV[0] + 4 * m, z[0], z[1], z[2], z[3], tid);
                 }
                 guard_flush(ex);
             });
-
+            ex.stamp(as_snapshot ? 5 : 6);  // plane-0 emission (5: snapshot, 6: log)
+            // 5c. bitmaps + higher planes
+            bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
+            if (!as_snapshot) bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
+            ex.stamp(7);  // T / eqB bitmaps
+            dac_finish<C>(ex, DV, io, sh.bmV0, sh.bmV1(), sh.prefV, listV, &sh.nlistV);
+            ex.stamp(8);  // Lmax Dac: bitmaps + planes >= 1
+            dac_finish<C>(ex, DM, io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
+            ex.stamp(9);  // Lmin Dac: planes >= 1
         }
-        ex.stamp(as_snapshot ? 5 : 6);  // plane-0 emission (5: snapshot, 6: log)
-        // 5c. bitmaps + higher planes
-        bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
-        if (!as_snapshot) bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
-        ex.stamp(7);  // T / eqB bitmaps
-        dac_finish<C>(ex, DV, io, sh.bmV0, sh.bmV1(), sh.prefV(), listV, &sh.nlistV);
-        ex.stamp(8);  // Lmax Dac: bitmaps + planes >= 1
-        dac_finish<C>(ex, DM, io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
-        ex.stamp(9);  // Lmin Dac: planes >= 1
 
         off += isize;
         blk_count++;
