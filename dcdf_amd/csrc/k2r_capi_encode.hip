@@ -218,14 +218,16 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
     if (rc != DCDF_OK) return rc;
     K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
     if (std::getenv("K2R_PROFILE_PRINT")) {
-        uint64_t acc[12] = {0};
+        uint64_t acc[NPROF] = {0};
         for (size_t i = 0; i < n; i++)
-            for (int k = 0; k < 12; k++) acc[k] += e->results[i].prof[k];
+            for (int k = 0; k < NPROF; k++) acc[k] += e->results[i].prof[k];
         uint64_t tot = 0;
-        for (int k = 0; k < 12; k++) tot += acc[k];
-        static const char* names[12] = {"p1 load+analysis", "p2 top", "p3 own/top nodes", "scan8", "sizes+clear+hdr",
-                                        "emit C snapshot", "emit C log", "T/eqB bitmaps", "Lmax dac", "Lmin dac", "emit pass A", "emit pass B"};
-        for (int k = 0; k < 12; k++)
+        for (int k = 0; k < NPROF; k++) tot += acc[k];
+        static const char* names[NPROF] = {"p1 load+analysis", "p2 top", "p3 own/top nodes", "reduce4", "clear+hdr",
+                                           "emit C snapshot", "emit C/Q log", "T/eqB bitmaps", "Lmax dac | V0,M0 bitmaps", "Lmin dac | zero bitmaps",
+                                           "emit pass A", "emit pass B/I", "sizes+heuristic", "winner scan", "byte-1 pass A", "byte-1 pass I",
+                                           "byte-1 pass Q", "-", "-", "-"};
+        for (int k = 0; k < NPROF; k++)
             std::fprintf(stderr, "k2r-prof %-18s %14llu cyc %5.1f%%\n", names[k], (unsigned long long)acc[k],
                          tot ? 100.0 * (double)acc[k] / (double)tot : 0.0);
     }

@@ -54,6 +54,7 @@ struct TileArgs {  // one Chunk::build input (device-visible copy of dcdf_tile_d
     uint32_t _pad;
 };
 
+constexpr int NPROF = 20;
 struct TileResult {
     int32_t status;
     uint32_t snapshots;
@@ -62,7 +63,7 @@ struct TileResult {
     uint64_t len;
     uint32_t dbg[6];  // guard record when status == ST_INTERNAL: count, code, instant, tid, value, limit
     uint32_t _pad2[2];
-    uint64_t prof[12];  // shader-clock cycles per phase (only filled by -DK2R_PROFILE diagnostic builds)
+    uint64_t prof[NPROF];  // shader-clock cycles per phase (only filled by -DK2R_PROFILE diagnostic builds)
 };
 
 K2R_HD uint32_t popc32(uint32_t x) { return (uint32_t)__builtin_popcount(x); }

@@ -59,8 +59,8 @@ struct EncShared {
     uint32_t bmV0[C::WV + 1];
     uint32_t bmM[2][C::WT + 1];
     uint32_t prefM[C::WT + 2];
-    uint64_t wsum[C::NW][MAX_SCAN_FIELDS];
-    uint64_t tot[MAX_SCAN_FIELDS];
+    uint32_t wsum[C::NW][MAX_SCAN_FIELDS];
+    uint32_t tot[MAX_SCAN_FIELDS];
     // One pool of LDS words with three lives per instant:
     //  (1) phase 1 .. plane-0 emission of a Log: the STASH.  While the cells of a block are in registers, phase 1
     //      records everything the emission of the log candidate will need below height 2 -- one 5-word I record per
@@ -85,15 +85,15 @@ struct EncShared {
     int32_t err;
     uint32_t work;
     uint32_t fault[6];  // [0] = count, [1..5] = first record (code, instant, tid, value, limit)
-    uint64_t prof[12], prof_last;  // -DK2R_PROFILE only
+    uint64_t prof[NPROF], prof_last;  // -DK2R_PROFILE only
 };
 
 struct EncRegs {
     // summaries of the four height-2 nodes of this thread's 8x8 block, carried from analysis to emission
     int32_t mn2[4], mx2[4], smn2[4], smx2[4];
     uint32_t flags;  // bit j: eq2[j] (all cells of node j differ from the snapshot by one constant)
-    uint64_t sc[MAX_SCAN_FIELDS];
-    uint64_t pf_lo, pf_top;  // saved exclusive prefixes of the chosen candidate
+    uint32_t sc[MAX_SCAN_FIELDS];  // words handed to ex.scan<>/ex.reduce<> (layout: see phase 3)
+    uint64_t pf_lo;                // saved exclusive prefix of the chosen candidate's lo pack
 };
 
 // ---- packed scan fields ------------------------------------------------------------------
@@ -148,8 +148,6 @@ struct Cls {  // counts of values needing > 1, > 2, > 3 bytes
         c2 += on ? o.c2 : 0u;
         c3 += on ? o.c3 : 0u;
     }
-    K2R_HD uint64_t pack18() const { return (uint64_t)c1 | ((uint64_t)c2 << 18) | ((uint64_t)c3 << 36); }
-    K2R_HD uint64_t pack16() const { return (uint64_t)c1 | ((uint64_t)c2 << 16) | ((uint64_t)c3 << 32); }
 };
 
 // ---- geometry helpers ---------------------------------------------------------------------
@@ -515,57 +513,6 @@ K2R_HD void bitmap_finish_write(EX& ex, const uint32_t* bm, uint32_t nbits, uint
     });
 }
 
-// One pass over up to four LDS bitmaps at once (T, eqB, and plane 0 of both Dacs): a single 4-field workgroup
-// scan of per-thread popcounts, then every thread serializes its own word range of each bitmap -- header,
-// rank index (bitmap.rs:97-104) and big-endian words (bitmap.rs:128-138) -- and leaves the per-word prefix
-// (needed for ranks on the Dac continuation bitmaps) in `pref`.
-struct BmJob {
-    const uint32_t* bm;  // LDS words
-    uint32_t nbits;
-    uint32_t* pref;      // LDS, may be null
-    uint8_t* dst;        // serialized BitMap goes here; null = bitmap absent
-};
-K2R_HD void gstore32u(uint8_t* p, uint32_t v);
-template <class C, class EX>
-K2R_HD void bitmaps_finish4(EX& ex, const BmJob (&J)[4]) {
-    constexpr int NT = C::NT;
-    ex.par_nosync([&](int tid, EncRegs& r) {
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            uint32_t sum = 0;
-            if (J[f].dst) {
-                const uint32_t W = (J[f].nbits + 31) / 32, CH = (W + NT - 1) / NT, w0 = (uint32_t)tid * CH;
-                for (uint32_t w = w0; w < w0 + CH && w < W; w++) sum += popc32(J[f].bm[w]);
-            }
-            r.sc[f] = sum;
-        }
-    });
-    ex.template scan<4>();
-    ex.par([&](int tid, EncRegs& r) {
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            if (!J[f].dst) continue;
-            const uint32_t nbits = J[f].nbits, W = (nbits + 31) / 32, CH = (W + NT - 1) / NT, w0 = (uint32_t)tid * CH;
-            const uint32_t nidx = nbits / 128;  // bitmap.rs:70
-            uint8_t* const dst = J[f].dst;
-            uint8_t* const wd = dst + 8 + 4 * nidx;
-            if (tid == 0) {
-                gstore32u(dst, __builtin_bswap32(nbits));
-                gstore32u(dst + 4, __builtin_bswap32(4u));  // k, bitmap.rs:69,130
-            }
-            uint32_t run = (uint32_t)r.sc[f];
-            for (uint32_t w = w0; w < w0 + CH && w < W; w++) {
-                const uint32_t x = J[f].bm[w];
-                if (J[f].pref) J[f].pref[w] = run;
-                run += popc32(x);
-                gstore32u(wd + 4 * w, __builtin_bswap32(x));
-                if ((w & 3u) == 3u && (w >> 2) < nidx) gstore32u(dst + 8 + 4 * (w >> 2), __builtin_bswap32(run));
-            }
-            if (J[f].pref && w0 < W && w0 + CH >= W) J[f].pref[W] = run;  // total, for rank(len)
-        }
-    });
-}
-
 // ---- emission sink ---------------------------------------------------------------------------------
 // One Dac being written: plane-0 bytes go straight to memory, longer values go to the overflow list.
 struct DacSink {
@@ -775,7 +722,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             sh.stI = 0;
             sh.stQ = 0;
             for (int i = 0; i < 6; i++) sh.fault[i] = 0;
-            for (int i = 0; i < 12; i++) sh.prof[i] = 0;
+            for (int i = 0; i < NPROF; i++) sh.prof[i] = 0;
             if (cap >= 6) {
                 out[0] = (uint8_t)ta.dtype;
                 out[1] = (uint8_t)ta.fbits;
@@ -907,9 +854,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             const bool P3S = !inv3 && mn3 != mx3;
             sh.tmin[tid] = mn3;
             sh.tmax[tid] = mx3;
-            // scan/reduce fields: [0] snapshot lo pack, [1] snapshot top pack | log c1(max) << 30 | log c1(min) << 48,
-            //                     [2] log lo pack, [3] log top pack | "wide" requests << 40
-            r.sc[0] = (uint64_t)sI1 | ((uint64_t)sI2 << 16);
+            // reduce words (completed in phase 3): [0] snapshot I1 | I2 << 16, [3] log I1 | I2 << 16,
+            //                                      [5] log c1(max) | c1(min) << 17
+            r.sc[0] = sI1 | (sI2 << 16);
             (void)P3S;
             if (have_s) {
                 const int32_t smn3 = min4(r.smn2[0], r.smn2[1], r.smn2[2], r.smn2[3]);
@@ -931,8 +878,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.tbS[tid] = 0;
                 sh.tbL[tid] = 0;
             }
-            r.sc[2] = (uint64_t)lI1 | ((uint64_t)lI2 << 16);
-            r.sc[1] = ((uint64_t)lMax.c1 << 30) | ((uint64_t)lMin.c1 << 48);
+            r.sc[3] = lI1 | (lI2 << 16);
+            r.sc[5] = lMax.c1 | (lMin.c1 << 17);
             if (err != 0) ex.lds_min(&sh.err, err);
         });
         const int32_t perr = ex.uni(sh.err);
@@ -1010,16 +957,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 
         // ================= phase 3: own node + (for the first NTOPX threads) one top node each ==========
         ex.par([&](int tid, EncRegs& r) {
-            uint64_t sLo = r.sc[0], lLo = r.sc[2];
+            uint32_t sI3 = 0, lI3 = 0;
             uint32_t wide = (r.flags >> 28) & 1u;
             Cls lMax, lMin;
-            uint64_t sTop = 0, lTop = 0;
+            uint32_t sTop = 0, lTop = 0;
             auto node = [&](int h, uint32_t j) {
                 if (PS(h, j)) {
-                    if (h == 3) sLo += 1ull << 30;
+                    if (h == 3) sI3 = 1;
                     else {
                         ex.lds_or(&sh.tbS[tbit(h, j) >> 5], 1u << (tbit(h, j) & 31));
-                        sTop += packTop(h);
+                        sTop += (uint32_t)packTop(h);
                     }
                 }
                 if (have_s) {
@@ -1030,10 +977,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     lMin.add1(vn, pL);
                     wide |= ((visL && (vx < -32768 || vx > 32767)) || (pL && (vn < -32768 || vn > 32767))) ? 1u : 0u;
                     if (pL) {
-                        if (h == 3) lLo += 1ull << 30;
+                        if (h == 3) lI3 = 1;
                         else {
                             ex.lds_or(&sh.tbL[tbit(h, j) >> 5], 1u << (tbit(h, j) & 31));
-                            lTop += packTop(h);
+                            lTop += (uint32_t)packTop(h);
                         }
                     }
                 }
@@ -1049,20 +996,22 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 top_decode((uint32_t)tid, h, j);
                 node(h, j);
             }
-            // fields: [0] snapshot lo pack, [1] snapshot top pack | log c1(max) << 30 | log c1(min) << 48,
-            //         [2] log lo pack, [3] log top pack | wide requests << 40
-            r.sc[0] = sLo;
-            r.sc[1] += sTop + ((uint64_t)lMax.c1 << 30) + ((uint64_t)lMin.c1 << 48);
-            r.sc[2] = lLo;
-            r.sc[3] = lTop + ((uint64_t)wide << 40);
+            // reduce words: [0] snapshot I1 | I2 << 16   [1] snapshot I3 | log I3 << 16   [2] snapshot top pack
+            //               [3] log I1 | I2 << 16        [4] log top pack                 [5] log c1(max) | c1(min) << 17
+            //               [6] "wide" requests
+            r.sc[1] = sI3 | (lI3 << 16);
+            r.sc[2] = sTop;
+            r.sc[4] = lTop;
+            r.sc[5] += lMax.c1 + (lMin.c1 << 17);
+            r.sc[6] = wide;
         });
         ex.stamp(2);  // phase 3: own/top nodes
-        ex.template reduce<4>();
+        ex.template reduce<7>();
         ex.stamp(3);  // totals of the 4 packed fields
 
         // Exact byte classes of EVERY value of one candidate (0 = snapshot, 1 = log): a second streaming pass over
         // the tile with compact rolled loops, run only when the exact figure matters (see phase 4).  Totals end up
-        // in sh.tot[4] (Lmax, pack18) and sh.tot[5] (Lmin, pack16).
+        // in sh.tot[8..10] (Lmax: > 1, > 2, > 3 bytes) and sh.tot[11..13] (Lmin).
         auto classes_pass = [&](const int which) {
 #ifdef K2R_SIM_TRACE
             if (EX::kSim) __builtin_printf("classes_pass(%d) inst=%u\n", which, inst);
@@ -1139,35 +1088,37 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         }
                     }
                 }
-                r.sc[4] = vMax.pack18();
-                r.sc[5] = vMin.pack16();
+                r.sc[8] = vMax.c1;
+                r.sc[9] = vMax.c2;
+                r.sc[10] = vMax.c3;
+                r.sc[11] = vMin.c1;
+                r.sc[12] = vMin.c2;
+                r.sc[13] = vMin.c3;
             });
-            ex.template reduce<2, 4>();
+            ex.template reduce<6, 8>();
         };
 
         // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
         Totals<C> TS, TL;
-        const uint64_t tot1 = ex.uni(sh.tot[1]);
-        TS.from(ex.uni(sh.tot[0]), tot1 & 0x3fffffffull);
+        const uint32_t t0 = ex.uni(sh.tot[0]), t1 = ex.uni(sh.tot[1]), t2 = ex.uni(sh.tot[2]);
+        TS.from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);
         DacLayout LV{}, LM{};
         uint32_t log_size = 0, log_eq_off = 0;
         bool log_narrow = false;  // every log value below height 3 fits 16 bits (what the stash stores)
         const bool cap254 = have_s && (blk_count - 1 == 254);  // chunk.rs:62 (checked first)
         if (have_s) {
-            const uint64_t tot3 = ex.uni(sh.tot[3]);
-            TL.from(ex.uni(sh.tot[2]), tot3 & 0x3fffffffull);
-            uint64_t lx = (tot1 >> 30) & 0x3ffff, ln = tot1 >> 48;  // only "> 1 byte" counts are kept inline
-            log_narrow = (tot3 >> 40) == 0;
+            const uint32_t t3 = ex.uni(sh.tot[3]), t4 = ex.uni(sh.tot[4]), t5 = ex.uni(sh.tot[5]), t6 = ex.uni(sh.tot[6]);
+            TL.from((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30), t4);
+            uint32_t lx1 = t5 & 0x1ffffu, lx2 = 0, lx3 = 0, ln1 = t5 >> 17, ln2 = 0, ln3 = 0;  // only "> 1 byte" counts are kept inline
+            log_narrow = t6 == 0;
             if (!log_narrow) {  // some log value may need 3+ bytes: count exactly
                 classes_pass(1);
-                lx = ex.uni(sh.tot[4]);
-                ln = ex.uni(sh.tot[5]);
+                lx1 = ex.uni(sh.tot[8]); lx2 = ex.uni(sh.tot[9]); lx3 = ex.uni(sh.tot[10]);
+                ln1 = ex.uni(sh.tot[11]); ln2 = ex.uni(sh.tot[12]); ln3 = ex.uni(sh.tot[13]);
             }
             log_eq_off = 13 + bitmap_size(TL.LT);
-            LV = dac_layout(log_eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, (uint32_t)(lx & 0x3ffff),
-                            (uint32_t)((lx >> 18) & 0x3ffff), (uint32_t)((lx >> 36) & 0x3ffff));
-            LM = dac_layout(LV.end, TL.M0, (uint32_t)(ln & 0xffff), (uint32_t)((ln >> 16) & 0xffff),
-                            (uint32_t)((ln >> 32) & 0xffff));
+            LV = dac_layout(log_eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, lx1, lx2, lx3);
+            LM = dac_layout(LV.end, TL.M0, ln1, ln2, ln3);
             log_size = LM.end;  // log.rs:95-97
         }
         // Snapshot size (snapshot.rs:87-92).  With every value at its minimum of one byte it is a lower bound that
@@ -1179,11 +1130,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         uint32_t snap_size = SM.end;
         if (!have_s || cap254 || snap_size <= log_size) {
             classes_pass(0);
-            const uint64_t sx = ex.uni(sh.tot[4]), sn = ex.uni(sh.tot[5]);
-            SV = dac_layout(sbase, TS.N0, (uint32_t)(sx & 0x3ffff), (uint32_t)((sx >> 18) & 0x3ffff),
-                            (uint32_t)((sx >> 36) & 0x3ffff));
-            SM = dac_layout(SV.end, TS.M0, (uint32_t)(sn & 0xffff), (uint32_t)((sn >> 16) & 0xffff),
-                            (uint32_t)((sn >> 32) & 0xffff));
+            SV = dac_layout(sbase, TS.N0, ex.uni(sh.tot[8]), ex.uni(sh.tot[9]), ex.uni(sh.tot[10]));
+            SM = dac_layout(SV.end, TS.M0, ex.uni(sh.tot[11]), ex.uni(sh.tot[12]), ex.uni(sh.tot[13]));
             snap_size = SM.end;
         }
         const bool as_snapshot = !have_s || cap254 || snap_size <= log_size;
@@ -1218,11 +1166,14 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         const Totals<C> TT = as_snapshot ? TS : TL;
         const DacLayout DV = as_snapshot ? SV : LV;
         const DacLayout DM = as_snapshot ? SM : LM;
+        ex.stamp(12);  // sizes + heuristic (wave-uniform arithmetic, lazy class passes)
         // exclusive prefixes of the winner's internal counts (positions)
         ex.par_nosync([&](int, EncRegs& r) {
-            r.sc[0] = as_snapshot ? r.sc[0] : r.sc[2];
+            r.sc[0] = as_snapshot ? r.sc[0] : r.sc[3];                      // I1 | I2 << 16
+            r.sc[1] = as_snapshot ? (r.sc[1] & 0xffffu) : (r.sc[1] >> 16);  // I3
         });
-        ex.template scan<1>();
+        ex.template scan<2>();
+        ex.stamp(13);  // scan of the winner's counts
 
         // ================= phase 5: emission of the winner ===============================================
         // 5a. clear bitmaps, save prefixes, header
@@ -1234,8 +1185,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
             for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV0[w] = 0;
             for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
-            r.pf_lo = r.sc[0];
-            sh.pfx[tid] = (uint32_t)(r.sc[0] & 0x3fffffffull);
+            r.pf_lo = (uint64_t)r.sc[0] | ((uint64_t)r.sc[1] << 30);  // the lo pack of unpackI
+            sh.pfx[tid] = r.sc[0];
             if (tid == 0) {
 #pragma unroll
                 for (int h = 0; h <= H; h++) {
@@ -1418,8 +1369,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             ex.stamp(8);
             if (DV.nlev > 1 || DM.nlev > 1) {
                 passA(P1{});
+                ex.stamp(14);
                 passI(P1{});
+                ex.stamp(15);
                 passQ(P1{});
+                ex.stamp(16);
                 if (DV.nlev > 1) bitmap_write_zero<C>(ex, DV.n[1], io + DV.bm_off[1]);
                 if (DM.nlev > 1) bitmap_write_zero<C>(ex, DM.n[1], io + DM.bm_off[1]);
             }
@@ -1555,7 +1509,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             res->stash_logs = n_stash;
             res->len = (status == ST_OK && !faulted) ? off : 0;
             for (int i = 0; i < 6; i++) res->dbg[i] = sh.fault[i];
-            for (int i = 0; i < 12; i++) res->prof[i] = sh.prof[i];
+            for (int i = 0; i < NPROF; i++) res->prof[i] = sh.prof[i];
         }
     });
 }

@@ -13,7 +13,7 @@
 
 namespace k2r {
 
-constexpr int MAX_SCAN_FIELDS = 8;
+constexpr int MAX_SCAN_FIELDS = 16;  // 32-bit words per thread that scan<>/reduce<> can combine
 
 #if defined(__HIPCC__)
 
@@ -68,7 +68,21 @@ struct GpuExec {
         return ((uint64_t)hi << 32) | lo;
     }
 
-    // workgroup sum of r.sc[0..NF) -> sh.tot[0..NF) (no prefixes): wave butterfly + one LDS atomic per wave
+    // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row_shr 1/2/4/8 inside each row of 16, then
+    // row_bcast:15 / row_bcast:31 to carry row totals): ten VALU instructions and no LDS traffic, where a
+    // __shfl_up ladder costs six dependent ds_bpermute round trips.  Inactive lanes contribute 0.
+    __device__ __forceinline__ static uint32_t wave_incl_scan(uint32_t v) {
+        int x = (int)v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+        x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+        return (uint32_t)x;
+    }
+
+    // workgroup sum of r.sc[F0..F0+NF) -> sh.tot[F0..F0+NF) (no prefixes): wave scan + one LDS atomic per wave
     template <int NF, int F0 = 0>
     __device__ __forceinline__ void reduce() {
         constexpr int W = NT < 64 ? NT : 64;
@@ -76,10 +90,9 @@ struct GpuExec {
         lds_barrier();
 #pragma unroll
         for (int f = F0; f < F0 + NF; f++) {
-            uint64_t v = r.sc[f];
-#pragma unroll
-            for (int d = W / 2; d >= 1; d >>= 1) v += __shfl_xor((unsigned long long)v, d, 64);
-            if ((tid & 63) == 0) atomicAdd((unsigned long long*)&sh.tot[f], (unsigned long long)v);
+            const uint32_t inc = wave_incl_scan(r.sc[f]);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, W - 1);
+            if ((tid & 63) == 0) atomicAdd(&sh.tot[f], total);
         }
         lds_barrier();
     }
@@ -94,27 +107,21 @@ struct GpuExec {
         constexpr int W = NT < 64 ? NT : 64;    // active lanes per wave
         constexpr int NW = NT < 64 ? 1 : NT / 64;
         const int lane = tid & 63;
-        const int wave = tid >> 6;
-        uint64_t incl[NF];
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        uint32_t incl[NF];
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            uint64_t v = r.sc[f];
-#pragma unroll
-            for (int d = 1; d < W; d <<= 1) {
-                uint64_t o = __shfl_up((unsigned long long)v, (unsigned)d, 64);
-                if (lane >= d) v += o;
-            }
-            incl[f] = v;
-            if (lane == W - 1) sh.wsum[wave][f] = v;
+            incl[f] = wave_incl_scan(r.sc[f]);
+            if (lane == W - 1) sh.wsum[wave][f] = incl[f];
         }
         lds_barrier();
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            uint64_t base = 0, tot = 0;
+            uint32_t base = 0, tot = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) {
-                uint64_t s = sh.wsum[w][f];
-                if (w < wave) base += s;
+                const uint32_t s = sh.wsum[w][f];
+                base += (w < wave) ? s : 0u;
                 tot += s;
             }
             r.sc[f] = base + incl[f] - r.sc[f];
@@ -157,7 +164,7 @@ struct SimExec {
     template <int NF, int F0 = 0>
     void reduce() {
         for (int f = F0; f < F0 + NF; f++) {
-            uint64_t run = 0;
+            uint32_t run = 0;
             for (int t = 0; t < NT; t++) run += regs[t].sc[f];
             sh.tot[f] = run;
         }
@@ -182,9 +189,9 @@ struct SimExec {
     template <int NF>
     void scan() {
         for (int f = 0; f < NF; f++) {
-            uint64_t run = 0;
+            uint32_t run = 0;
             for (int t = 0; t < NT; t++) {
-                uint64_t v = regs[t].sc[f];
+                const uint32_t v = regs[t].sc[f];
                 regs[t].sc[f] = run;
                 run += v;
             }
