@@ -80,6 +80,8 @@ struct EncShared {
     uint32_t pfx[C::NBLK];  // per-thread exclusive prefix of the winner's lo pack (I1 | I2 << 16), for stash emission
     uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
     uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
+    uint32_t tbP[C::TBW + 1];           // per-word exclusive popcount prefix of the winner's flags
+    uint32_t ttR[C::H + 2];             // rank (over those flags) of the first node of height h
     uint32_t nlistV, nlistM;
     uint32_t stI, stQ;  // stash record counters
     int32_t err;
@@ -94,6 +96,7 @@ struct EncRegs {
     uint32_t flags;  // bit j: eq2[j] (all cells of node j differ from the snapshot by one constant)
     uint32_t sc[MAX_SCAN_FIELDS];  // words handed to ex.scan<>/ex.reduce<> (layout: see phase 3)
     uint64_t pf_lo;                // saved exclusive prefix of the chosen candidate's lo pack
+    uint32_t pa[9];                // what pass A emitted (positions, second bytes), replayed by the byte-1 pass
 };
 
 // ---- packed scan fields ------------------------------------------------------------------
@@ -454,6 +457,9 @@ enum : uint32_t {
 // bit p lives in word p/32 at position 31-(p%32)  (bitmap.rs:176-183)
 template <class EX>
 K2R_HD void bm_set(EX& ex, uint32_t* bm, uint32_t p) {
+#ifdef K2R_X_NOATOMIC
+    return;
+#endif
     ex.lds_or(&bm[p >> 5], 0x80000000u >> (p & 31));
 }
 // OR a run of `len` (1..32) bits starting at bit position p; bits are right-aligned in `bits`,
@@ -461,6 +467,9 @@ K2R_HD void bm_set(EX& ex, uint32_t* bm, uint32_t p) {
 template <class EX>
 K2R_HD void bm_or_run(EX& ex, uint32_t* bm, uint32_t p, uint32_t len, uint32_t bits) {
     if (len == 0 || bits == 0) return;
+#ifdef K2R_X_NOATOMIC
+    return;
+#endif
     const uint64_t v = (uint64_t)bits << (64 - len);  // left-aligned in 64
     const uint32_t sh = p & 31;
     const uint64_t w = v >> sh;  // occupies bits of words (p>>5) and (p>>5)+1
@@ -510,6 +519,55 @@ K2R_HD void bitmap_finish_write(EX& ex, const uint32_t* bm, uint32_t nbits, uint
         for (uint32_t b = (uint32_t)tid; b < nidx; b += NT) gstore32u(dst + 8 + 4 * b, __builtin_bswap32(pref[4 * (b + 1)]));
         uint8_t* wd = dst + 8 + 4 * nidx;
         for (uint32_t w = (uint32_t)tid; w < W; w += NT) gstore32u(wd + 4 * w, __builtin_bswap32(bm[w]));
+    });
+}
+
+// Several LDS bitmaps finished in one go: one multi-field workgroup scan of per-thread popcounts, then every thread
+// serializes its own word range of each bitmap -- header, rank index (bitmap.rs:97-104) and big-endian words
+// (bitmap.rs:128-138) -- and leaves the per-word rank prefix in `pref` where one is asked for.
+struct BmJob {
+    const uint32_t* bm;  // LDS words
+    uint32_t nbits;
+    uint32_t* pref;      // LDS, may be null
+    uint8_t* dst;        // where the serialized BitMap goes; null = bitmap absent
+};
+template <class C, int NB, class EX>
+K2R_HD void bitmaps_finish(EX& ex, const BmJob (&J)[NB]) {
+    constexpr int NT = C::NT;
+    ex.par_nosync([&](int tid, EncRegs& r) {
+#pragma unroll
+        for (int f = 0; f < NB; f++) {
+            uint32_t sum = 0;
+            if (J[f].dst) {
+                const uint32_t W = (J[f].nbits + 31) / 32, CH = (W + NT - 1) / NT, w0 = (uint32_t)tid * CH;
+                for (uint32_t w = w0; w < w0 + CH && w < W; w++) sum += popc32(J[f].bm[w]);
+            }
+            r.sc[f] = sum;
+        }
+    });
+    ex.template scan<NB>();
+    ex.par([&](int tid, EncRegs& r) {
+#pragma unroll
+        for (int f = 0; f < NB; f++) {
+            if (!J[f].dst) continue;
+            const uint32_t nbits = J[f].nbits, W = (nbits + 31) / 32, CH = (W + NT - 1) / NT, w0 = (uint32_t)tid * CH;
+            const uint32_t nidx = nbits / 128;  // bitmap.rs:70
+            uint8_t* const dst = J[f].dst;
+            uint8_t* const wd = dst + 8 + 4 * nidx;
+            if (tid == 0) {
+                gstore32u(dst, __builtin_bswap32(nbits));
+                gstore32u(dst + 4, __builtin_bswap32(4u));  // k, bitmap.rs:69,130
+            }
+            uint32_t run = r.sc[f];
+            for (uint32_t w = w0; w < w0 + CH && w < W; w++) {
+                const uint32_t x = J[f].bm[w];
+                if (J[f].pref) J[f].pref[w] = run;
+                run += popc32(x);
+                gstore32u(wd + 4 * w, __builtin_bswap32(x));
+                if ((w & 3u) == 3u && (w >> 2) < nidx) gstore32u(dst + 8 + 4 * (w >> 2), __builtin_bswap32(run));
+            }
+            if (J[f].pref && w0 < W && w0 + CH >= W) J[f].pref[W] = run;  // total, for rank(len)
+        }
     });
 }
 
@@ -1187,6 +1245,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
             r.pf_lo = (uint64_t)r.sc[0] | ((uint64_t)r.sc[1] << 30);  // the lo pack of unpackI
             sh.pfx[tid] = r.sc[0];
+            if (tid <= C::TBW) {  // rank prefix over the winner's top-node flags (<= 12 words)
+                const uint32_t* const tbw = as_snapshot ? sh.tbS : sh.tbL;
+                uint32_t run = 0;
+                for (int w = 0; w < tid && w < C::TBW; w++) run += popc32(tbw[w]);
+                sh.tbP[tid] = run;
+            }
             if (tid == 0) {
 #pragma unroll
                 for (int h = 0; h <= H; h++) {
@@ -1194,6 +1258,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     sh.ttI[h] = TT.offI[h];
                     sh.ttZ[h] = TT.offZ[h];
                 }
+                uint32_t rr = 0;
+#pragma unroll
+                for (int h = 4; h <= H; h++) {
+                    sh.ttR[h] = rr;
+                    rr += TT.Ni[h];
+                }
+                sh.ttR[H + 1] = rr;
                 sh.nlistV = 0;
                 sh.nlistM = 0;
                 if (do_patch) out[hdr_patch_off] = (uint8_t)hdr_patch_val;
@@ -1227,32 +1298,56 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 
             // -- this thread's own height-3 node and, for the first NTOPX threads, one top node each --
             const uint32_t* const tb = as_snapshot ? sh.tbS : sh.tbL;
-            auto enode = [&](int h, uint32_t j) {
+            if (MODE == EM_P0) {
+                r.pa[2] = 0;
+                r.pa[6] = 0;
+                r.pa[8] = 0;
+            }
+            auto enode = [&](int h, uint32_t j, const int slot) {
                 const bool vis = (h == H) ? true : bit_test(tb, tbit(h + 1, j >> 2));
                 if (!vis) return;
                 const bool p = (h == 3) ? (as_snapshot ? PS(3, j) : PL(3, j)) : bit_test(tb, tbit(h, j));
                 // level-order index: four children per internal parent, parents ranked among the internal nodes
+                auto trank = [&](uint32_t b) -> uint32_t {  // set flags before bit b
+                    return sh.tbP[b >> 5] + popc32(tb[b >> 5] & ((1u << (b & 31u)) - 1u));
+                };
                 uint32_t vrank = 0;
-                if (h < H) vrank = 4 * bits_count(tb, tbit(h + 1, 0), tbit(h + 1, j >> 2)) + (j & 3);
+                if (h < H) vrank = 4 * (trank(tbit(h + 1, j >> 2)) - sh.ttR[h + 1]) + (j & 3);
                 const uint32_t idx = sh.ttV[h] + vrank;
-                const uint32_t irank = (h == 3) ? unpackI(3, pLo, 0) : bits_count(tb, tbit(h, 0), tbit(h, j));
-                emit_val<0, MODE>(ex, sinkV, idx, zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j)), tid);
+                const uint32_t irank = (h == 3) ? unpackI(3, pLo, 0) : trank(tbit(h, j)) - sh.ttR[h];
+                const uint32_t zv = zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j));
+                emit_val<0, MODE>(ex, sinkV, idx, zv, tid);
+                if (MODE == EM_P0) {
+                    r.pa[3 * slot] = idx;
+                    r.pa[2] |= (zv >> 8) << (16 * slot);
+                }
                 if (p) {
-                    if (MODE != EM_P1) bm_set(ex, sh.bmT, guard_pos(ex, idx, 1, TT.LT, kGuardTOwn));
-                    emit_val<1, MODE>(ex, sinkM, sh.ttI[h] + irank, zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j)), tid);
-                } else if (!as_snapshot && MODE != EM_P1) {
+                    bm_set(ex, sh.bmT, guard_pos(ex, idx, 1, TT.LT, kGuardTOwn));
+                    const uint32_t zm = zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j));
+                    emit_val<1, MODE>(ex, sinkM, sh.ttI[h] + irank, zm, tid);
+                    if (MODE == EM_P0) {
+                        r.pa[3 * slot + 1] = sh.ttI[h] + irank;
+                        r.pa[2] |= (zm >> 8) << (16 * slot + 8);
+                    }
+                } else if (!as_snapshot) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
                     if (e) bm_set(ex, sh.bmE, guard_pos(ex, sh.ttZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
                 }
             };
-            enode(3, (uint32_t)tid);
+            enode(3, (uint32_t)tid, 0);
+#ifdef K2R_X_STAMPS
+            ex.stamp(17);
+#endif
             if (tid < C::NTOPX) {
                 int h;
                 uint32_t j;
                 top_decode((uint32_t)tid, h, j);
-                enode(h, j);
+                enode(h, j, 1);
             }
+#ifdef K2R_X_STAMPS
+            ex.stamp(18);
+#endif
 
             // -- the four height-2 children of this thread's block + the work list of internal height-2 nodes --
             const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
@@ -1283,14 +1378,20 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
                 }
                 emit4<0, MODE>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
-                if (MODE != EM_P1) bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
-                if (!as_snapshot && MODE != EM_P1) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
+                if (MODE == EM_P0) {
+                    r.pa[5] = p2;
+                    r.pa[6] = (z2v[0] >> 8) | ((z2v[1] >> 8) << 8) | ((z2v[2] >> 8) << 16) | ((z2v[3] >> 8) << 24);
+                    r.pa[7] = TT.offI[2] + E2;
+                }
+                bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
+                if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
                 uint32_t n2 = 0, pre = E1;
                 const uint32_t cshift = as_snapshot ? 4u : 16u;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (P2[j]) {
                         emit_val<1, MODE>(ex, sinkM, TT.offI[2] + E2 + n2, zm2[j], tid);
+                        if (MODE == EM_P0) r.pa[8] |= (zm2[j] >> 8) << (8 * n2);
                         if (MODE == EM_LIST)
                             sh.L2()[guard_pos(ex, E2 + n2, 1, 4 * C::NBLK, kGuardList2)] = ((uint32_t)tid << 2) | (uint32_t)j | (pre << 12);
                         n2++;
@@ -1298,6 +1399,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                 }
             }
+#ifdef K2R_X_STAMPS
+            ex.stamp(19);
+#endif
             guard_flush(ex);
         });
         };
@@ -1360,15 +1464,47 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             ex.stamp(11);
             passQ(P0{});
             ex.stamp(6);
-            bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
-            bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
-            ex.stamp(7);
-            // continuation bitmaps of both Dacs (serialized + rank prefixes), then the second bytes
-            if (DV.nlev > 0) bitmap_finish_write<C>(ex, sh.bmV0, DV.n[0], sh.prefV, io + DV.bm_off[0]);
-            if (DM.nlev > 0) bitmap_finish_write<C>(ex, sh.bmM[0], DM.n[0], sh.prefM, io + DM.bm_off[0]);
+            // T, eqB and the continuation bitmaps of both Dacs (serialized; rank prefixes kept for the second bytes)
+            {
+                const BmJob jobs[4] = {{sh.bmT, TT.LT, nullptr, io + 13},
+                                       {sh.bmE, TT.LT - TT.M0, nullptr, io + log_eq_off},
+                                       {sh.bmV0, DV.n[0], sh.prefV, DV.nlev > 0 ? io + DV.bm_off[0] : nullptr},
+                                       {sh.bmM[0], DM.n[0], sh.prefM, DM.nlev > 0 ? io + DM.bm_off[0] : nullptr}};
+                bitmaps_finish<C, 4>(ex, jobs);
+            }
             ex.stamp(8);
             if (DV.nlev > 1 || DM.nlev > 1) {
-                passA(P1{});
+                // byte 1 of what pass A emitted, replayed from the registers it left behind
+                ex.par([&](int tid, EncRegs& r) {
+                    auto put = [&](const DacSink& d, uint32_t* bm0, uint32_t pos, uint32_t hi) {
+                        if (hi) {
+                            pos = guard_pos(ex, pos, 1, d.n0, d.code);
+                            gstore8(d.plane1 + guard_pos(ex, bm_rank(bm0, d.pref, pos), 1, d.n1, d.code + 1), (uint8_t)hi);
+                        }
+                    };
+                    auto put4 = [&](const DacSink& d, uint32_t* bm0, uint32_t pos, uint32_t his) {  // consecutive positions
+                        if (his) {
+                            pos = guard_pos(ex, pos, 4, d.n0 + 3, d.code);
+                            uint32_t q = bm_rank(bm0, d.pref, pos);
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const uint32_t b = (his >> (8 * i)) & 0xffu;
+                                if (b) {
+                                    gstore8(d.plane1 + guard_pos(ex, q, 1, d.n1, d.code + 1), (uint8_t)b);
+                                    q++;
+                                }
+                            }
+                        }
+                    };
+                    const uint32_t hb = r.pa[2];
+                    put(sinkV, sh.bmV0, r.pa[0], hb & 0xffu);
+                    put(sinkM, sh.bmM[0], r.pa[1], (hb >> 8) & 0xffu);
+                    put(sinkV, sh.bmV0, r.pa[3], (hb >> 16) & 0xffu);
+                    put(sinkM, sh.bmM[0], r.pa[4], hb >> 24);
+                    put4(sinkV, sh.bmV0, r.pa[5], r.pa[6]);
+                    put4(sinkM, sh.bmM[0], r.pa[7], r.pa[8]);
+                    guard_flush(ex);
+                });
                 ex.stamp(14);
                 passI(P1{});
                 ex.stamp(15);
