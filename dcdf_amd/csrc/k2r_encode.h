@@ -51,45 +51,6 @@ struct EncCfg {
     static constexpr int top_off(int h) { return ((1 << (2 * (H - 2))) - (1 << (2 * (H - h + 1)))) / 3; }
 };
 
-template <class C>
-struct EncShared {
-    int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
-    uint32_t eq[C::NTOP];
-    uint32_t bmT[C::WT + 1], bmE[C::WT + 1];
-    uint32_t bmV0[C::WV + 1];
-    uint32_t bmM[2][C::WT + 1];
-    uint32_t prefM[C::WT + 2];
-    uint32_t wsum[C::NW][MAX_SCAN_FIELDS];
-    uint32_t tot[MAX_SCAN_FIELDS];
-    // One pool of LDS words with three lives per instant:
-    //  (1) phase 1 .. plane-0 emission of a Log: the STASH.  While the cells of a block are in registers, phase 1
-    //      records everything the emission of the log candidate will need below height 2 -- one 5-word I record per
-    //      internal height-2 node (growing up from word 0) and one 3-word Q record per internal quad (growing down
-    //      from word POOLW) -- so that emitting a Log touches no input memory at all.
-    //  (2) plane-0 emission of a Snapshot, or of a Log whose stash overflowed / whose values do not fit 16 bits:
-    //      the work lists L2 (internal height-2 nodes) and L1 (internal quads) of the re-reading passes.
-    //  (3) Dac finishing in list mode: the second continuation bitmap of the Lmax Dac.
-    static constexpr int POOL_L1 = 4 * C::NBLK;                 // word offset of L1 (16*NBLK u16 = 8*NBLK words)
-    static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
-    static constexpr int POOLW = POOL_BMV1 + C::WV + 1 + (C::H == 8 ? 7280 : 0);  // sidelen 256: LDS filled to 160 KB
-    uint32_t pool[POOLW];
-    K2R_HD uint32_t* L2() { return pool; }                                  // key = blk<<2|j | (quads before) << 12
-    K2R_HD uint16_t* L1() { return (uint16_t*)(pool + POOL_L1); }           // key = blk<<4|j<<2|qq
-    K2R_HD uint32_t* bmV1() { return pool + POOL_BMV1; }
-    uint32_t prefV[C::WV + 2];  // per-word rank prefixes of the Lmax Dac's continuation bitmap
-    uint32_t pfx[C::NBLK];  // per-thread exclusive prefix of the winner's lo pack (I1 | I2 << 16), for stash emission
-    uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
-    uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
-    uint32_t tbP[C::TBW + 1];           // per-word exclusive popcount prefix of the winner's flags
-    uint32_t ttR[C::H + 2];             // rank (over those flags) of the first node of height h
-    uint32_t nlistV, nlistM;
-    uint32_t stI, stQ;  // stash record counters
-    int32_t err;
-    uint32_t work;
-    uint32_t fault[6];  // [0] = count, [1..5] = first record (code, instant, tid, value, limit)
-    uint64_t prof[NPROF], prof_last;  // -DK2R_PROFILE only
-};
-
 struct EncRegs {
     // summaries of the four height-2 nodes of this thread's 8x8 block, carried from analysis to emission
     int32_t mn2[4], mx2[4], smn2[4], smx2[4];
@@ -418,6 +379,59 @@ struct Totals {
         LT = offV[0];
         M0 = i;
     }
+};
+
+// What one lane decides per instant (phase 4) and every thread then reads from LDS: both candidates' level
+// offsets and Dac layouts, the winner, its size.  Keeping this in LDS rather than in (replicated, wave-uniform)
+// scalar registers is what keeps the kernel's register pressure in check.
+template <class C>
+struct InstPlan {
+    Totals<C> T[2];       // [0] snapshot candidate, [1] log candidate
+    DacLayout V[2], M[2]; // Lmax / Lmin Dac layouts of the candidates
+    uint32_t need;        // bit 0: exact byte classes of the log wanted, bit 1: of the snapshot (staged planning)
+    uint32_t narrow;      // every log value fits 16 bits
+    uint32_t log_size, snap_lb, eq_off;
+    uint32_t as_snapshot, use_stash, isize;
+};
+
+template <class C>
+struct EncShared {
+    int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
+    uint32_t eq[C::NTOP];
+    uint32_t bmT[C::WT + 1], bmE[C::WT + 1];
+    uint32_t bmV0[C::WV + 1];
+    uint32_t bmM[2][C::WT + 1];
+    uint32_t prefM[C::WT + 2];
+    uint32_t wsum[C::NW][MAX_SCAN_FIELDS];
+    uint32_t tot[MAX_SCAN_FIELDS];
+    // One pool of LDS words with three lives per instant:
+    //  (1) phase 1 .. plane-0 emission of a Log: the STASH.  While the cells of a block are in registers, phase 1
+    //      records everything the emission of the log candidate will need below height 2 -- one 5-word I record per
+    //      internal height-2 node (growing up from word 0) and one 3-word Q record per internal quad (growing down
+    //      from word POOLW) -- so that emitting a Log touches no input memory at all.
+    //  (2) plane-0 emission of a Snapshot, or of a Log whose stash overflowed / whose values do not fit 16 bits:
+    //      the work lists L2 (internal height-2 nodes) and L1 (internal quads) of the re-reading passes.
+    //  (3) Dac finishing in list mode: the second continuation bitmap of the Lmax Dac.
+    static constexpr int POOL_L1 = 4 * C::NBLK;                 // word offset of L1 (16*NBLK u16 = 8*NBLK words)
+    static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
+    static constexpr int POOLW = POOL_BMV1 + C::WV + 1 + (C::H == 8 ? 7000 : 0);  // sidelen 256: LDS filled to 160 KB
+    uint32_t pool[POOLW];
+    K2R_HD uint32_t* L2() { return pool; }                                  // key = blk<<2|j | (quads before) << 12
+    K2R_HD uint16_t* L1() { return (uint16_t*)(pool + POOL_L1); }           // key = blk<<4|j<<2|qq
+    K2R_HD uint32_t* bmV1() { return pool + POOL_BMV1; }
+    uint32_t prefV[C::WV + 2];  // per-word rank prefixes of the Lmax Dac's continuation bitmap
+    uint32_t pfx[C::NBLK];  // per-thread exclusive prefix of the winner's lo pack (I1 | I2 << 16), for stash emission
+    uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
+    uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
+    uint32_t tbP[C::TBW + 1];           // per-word exclusive popcount prefix of the winner's flags
+    uint32_t ttR[C::H + 2];             // rank (over those flags) of the first node of height h
+    uint32_t nlistV, nlistM;
+    uint32_t stI, stQ;  // stash record counters
+    InstPlan<C> pl;
+    int32_t err;
+    uint32_t work;
+    uint32_t fault[6];  // [0] = count, [1..5] = first record (code, instant, tid, value, limit)
+    uint64_t prof[NPROF], prof_last;  // -DK2R_PROFILE only
 };
 
 // ---- internal consistency guard --------------------------------------------------------------------
@@ -1157,42 +1171,97 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         };
 
         // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
-        Totals<C> TS, TL;
-        const uint32_t t0 = ex.uni(sh.tot[0]), t1 = ex.uni(sh.tot[1]), t2 = ex.uni(sh.tot[2]);
-        TS.from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);
-        DacLayout LV{}, LM{};
-        uint32_t log_size = 0, log_eq_off = 0;
-        bool log_narrow = false;  // every log value below height 3 fits 16 bits (what the stash stores)
+        // Planned by ONE lane into sh.pl (see InstPlan).  Sizes are functions of counts; the log's byte classes
+        // come inline from phase 1 unless a value may need 3+ bytes, the snapshot's are only counted when its
+        // one-byte-per-value lower bound does not already lose against the log (snapshot.rs:87-92, log.rs:95-97).
         const bool cap254 = have_s && (blk_count - 1 == 254);  // chunk.rs:62 (checked first)
-        if (have_s) {
-            const uint32_t t3 = ex.uni(sh.tot[3]), t4 = ex.uni(sh.tot[4]), t5 = ex.uni(sh.tot[5]), t6 = ex.uni(sh.tot[6]);
-            TL.from((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30), t4);
-            uint32_t lx1 = t5 & 0x1ffffu, lx2 = 0, lx3 = 0, ln1 = t5 >> 17, ln2 = 0, ln3 = 0;  // only "> 1 byte" counts are kept inline
-            log_narrow = t6 == 0;
-            if (!log_narrow) {  // some log value may need 3+ bytes: count exactly
-                classes_pass(1);
-                lx1 = ex.uni(sh.tot[8]); lx2 = ex.uni(sh.tot[9]); lx3 = ex.uni(sh.tot[10]);
-                ln1 = ex.uni(sh.tot[11]); ln2 = ex.uni(sh.tot[12]); ln3 = ex.uni(sh.tot[13]);
-            }
-            log_eq_off = 13 + bitmap_size(TL.LT);
-            LV = dac_layout(log_eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, lx1, lx2, lx3);
-            LM = dac_layout(LV.end, TL.M0, ln1, ln2, ln3);
-            log_size = LM.end;  // log.rs:95-97
+        auto plan = [&](const int stage) {
+            ex.par([&](int tid, EncRegs&) {
+                if (tid != 0) return;
+                auto& pl = sh.pl;
+                auto choose = [&](bool snap) {
+                    pl.as_snapshot = snap ? 1u : 0u;
+                    pl.isize = snap ? pl.M[0].end : pl.M[1].end;
+                    // a Log is emitted from the stash when phase 1 managed to record all of it
+                    pl.use_stash = (!snap && pl.narrow && 5u * stI + 3u * stQ <= stash_cap && stI == pl.T[1].Ni[2] &&
+                                    stQ == pl.T[1].Ni[1]) ? 1u : 0u;
+                    const Totals<C>& W = pl.T[snap ? 0 : 1];
+#pragma unroll
+                    for (int h = 0; h <= H; h++) {
+                        sh.ttV[h] = W.offV[h];
+                        sh.ttI[h] = W.offI[h];
+                        sh.ttZ[h] = W.offZ[h];
+                    }
+                    uint32_t rr = 0;
+#pragma unroll
+                    for (int h = 4; h <= H; h++) {
+                        sh.ttR[h] = rr;
+                        rr += W.Ni[h];
+                    }
+                    sh.ttR[H + 1] = rr;
+                    pl.need = 0;
+                };
+                if (stage == 1) {
+                    const uint32_t t0 = sh.tot[0], t1 = sh.tot[1], t2 = sh.tot[2];
+                    pl.T[0].from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);
+                    pl.need = 0;
+                    pl.narrow = 0;
+                    pl.log_size = 0;
+                    pl.eq_off = 0;
+                    if (have_s) {
+                        const uint32_t t3 = sh.tot[3], t4 = sh.tot[4], t5 = sh.tot[5], t6 = sh.tot[6];
+                        pl.T[1].from((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30), t4);
+                        pl.narrow = t6 == 0 ? 1u : 0u;
+                        pl.eq_off = 13 + bitmap_size(pl.T[1].LT);
+                        if (t6 == 0) {  // only "> 1 byte" counts are kept inline
+                            pl.V[1] = dac_layout(pl.eq_off + bitmap_size(pl.T[1].LT - pl.T[1].M0), pl.T[1].N0, t5 & 0x1ffffu, 0, 0);
+                            pl.M[1] = dac_layout(pl.V[1].end, pl.T[1].M0, t5 >> 17, 0, 0);
+                            pl.log_size = pl.M[1].end;  // log.rs:95-97
+                        } else {
+                            pl.need = 1;  // some log value may need 3+ bytes: count exactly first
+                        }
+                    }
+                    const uint32_t sbase = 13 + bitmap_size(pl.T[0].LT);
+                    pl.V[0] = dac_layout(sbase, pl.T[0].N0, 0, 0, 0);
+                    pl.M[0] = dac_layout(pl.V[0].end, pl.T[0].M0, 0, 0, 0);
+                    pl.snap_lb = pl.M[0].end;
+                    if (pl.need == 0) {
+                        if (!have_s || cap254 || pl.snap_lb <= pl.log_size) pl.need = 2;
+                        else choose(false);
+                    }
+                } else if (stage == 2) {  // exact classes of the log are in sh.tot[8..13]
+                    pl.V[1] = dac_layout(pl.eq_off + bitmap_size(pl.T[1].LT - pl.T[1].M0), pl.T[1].N0, sh.tot[8], sh.tot[9], sh.tot[10]);
+                    pl.M[1] = dac_layout(pl.V[1].end, pl.T[1].M0, sh.tot[11], sh.tot[12], sh.tot[13]);
+                    pl.log_size = pl.M[1].end;
+                    if (cap254 || pl.snap_lb <= pl.log_size) pl.need = 2;
+                    else choose(false);
+                } else {  // exact classes of the snapshot are in sh.tot[8..13]
+                    const uint32_t sbase = 13 + bitmap_size(pl.T[0].LT);
+                    pl.V[0] = dac_layout(sbase, pl.T[0].N0, sh.tot[8], sh.tot[9], sh.tot[10]);
+                    pl.M[0] = dac_layout(pl.V[0].end, pl.T[0].M0, sh.tot[11], sh.tot[12], sh.tot[13]);
+                    choose(!have_s || cap254 || pl.M[0].end <= pl.log_size);
+                }
+            });
+        };
+        plan(1);
+        uint32_t need = ex.uni(sh.pl.need);
+        if (need & 1u) {
+            classes_pass(1);
+            plan(2);
+            need = ex.uni(sh.pl.need);
         }
-        // Snapshot size (snapshot.rs:87-92).  With every value at its minimum of one byte it is a lower bound that
-        // costs nothing; only if that bound does not already exceed the log's size (or the snapshot is taken
-        // regardless) are the exact byte classes counted.
-        const uint32_t sbase = 13 + bitmap_size(TS.LT);
-        DacLayout SV = dac_layout(sbase, TS.N0, 0, 0, 0);
-        DacLayout SM = dac_layout(SV.end, TS.M0, 0, 0, 0);
-        uint32_t snap_size = SM.end;
-        if (!have_s || cap254 || snap_size <= log_size) {
+        if (need & 2u) {
             classes_pass(0);
-            SV = dac_layout(sbase, TS.N0, ex.uni(sh.tot[8]), ex.uni(sh.tot[9]), ex.uni(sh.tot[10]));
-            SM = dac_layout(SV.end, TS.M0, ex.uni(sh.tot[11]), ex.uni(sh.tot[12]), ex.uni(sh.tot[13]));
-            snap_size = SM.end;
+            plan(3);
         }
-        const bool as_snapshot = !have_s || cap254 || snap_size <= log_size;
+        const bool as_snapshot = ex.uni(sh.pl.as_snapshot) != 0;
+        const bool use_stash = ex.uni(sh.pl.use_stash) != 0;
+        const uint32_t isize = ex.uni(sh.pl.isize);
+        const uint32_t log_eq_off = ex.uni(sh.pl.eq_off);
+        // the winner's level offsets and Dac layouts: read from LDS where they are used
+        const Totals<C>& TT = sh.pl.T[as_snapshot ? 0 : 1];
+        const DacLayout& DV = sh.pl.V[as_snapshot ? 0 : 1];
+        const DacLayout& DM = sh.pl.M[as_snapshot ? 0 : 1];
 
         uint32_t hdr_patch_off = 0, hdr_patch_val = 0;
         bool do_patch = false;
@@ -1211,19 +1280,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         } else {
             n_log++;
         }
-        const uint32_t isize = as_snapshot ? snap_size : log_size;
         if ((uint64_t)off + isize > cap) {
             status = ST_OUT_CAPACITY;
             break;
         }
         uint8_t* const io = out + off;  // first byte of this Snapshot / Log
-        // A Log is emitted from the stash when phase 1 managed to record all of it (else: the re-reading passes)
-        const bool use_stash = !as_snapshot && log_narrow && 5u * stI + 3u * stQ <= stash_cap && stI == TL.Ni[2] &&
-                               stQ == TL.Ni[1];
         n_stash += use_stash ? 1u : 0u;
-        const Totals<C> TT = as_snapshot ? TS : TL;
-        const DacLayout DV = as_snapshot ? SV : LV;
-        const DacLayout DM = as_snapshot ? SM : LM;
         ex.stamp(12);  // sizes + heuristic (wave-uniform arithmetic, lazy class passes)
         // exclusive prefixes of the winner's internal counts (positions)
         ex.par_nosync([&](int, EncRegs& r) {
@@ -1235,7 +1297,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 
         // ================= phase 5: emission of the winner ===============================================
         // 5a. clear bitmaps, save prefixes, header
-        const uint32_t WTn = (TT.LT + 31) / 32, WVn = (TT.N0 + 31) / 32, WMn = (TT.M0 + 31) / 32;
+        const uint32_t WTn = (ex.uni(TT.LT) + 31) / 32, WVn = (ex.uni(TT.N0) + 31) / 32, WMn = (ex.uni(TT.M0) + 31) / 32;
         ex.par([&](int tid, EncRegs& r) {
             for (uint32_t w = (uint32_t)tid; w <= WTn; w += NT) {
                 sh.bmT[w] = 0;
@@ -1252,19 +1314,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.tbP[tid] = run;
             }
             if (tid == 0) {
-#pragma unroll
-                for (int h = 0; h <= H; h++) {
-                    sh.ttV[h] = TT.offV[h];
-                    sh.ttI[h] = TT.offI[h];
-                    sh.ttZ[h] = TT.offZ[h];
-                }
-                uint32_t rr = 0;
-#pragma unroll
-                for (int h = 4; h <= H; h++) {
-                    sh.ttR[h] = rr;
-                    rr += TT.Ni[h];
-                }
-                sh.ttR[H + 1] = rr;
                 sh.nlistV = 0;
                 sh.nlistM = 0;
                 if (do_patch) out[hdr_patch_off] = (uint8_t)hdr_patch_val;
@@ -1282,10 +1331,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         });
 
         ex.stamp(4);  // sizes, heuristic, clears, header
-        const DacSink sinkV{io + DV.by_off[0], sh.bmV0, listV, &sh.nlistV, DV.n[0], DV.n[1], inst, kGuardVPos,
-                            io + DV.by_off[1], sh.prefV};
-        const DacSink sinkM{io + DM.by_off[0], sh.bmM[0], listM, &sh.nlistM, DM.n[0], DM.n[1], inst, kGuardMPos,
-                            io + DM.by_off[1], sh.prefM};
+        const uint32_t nlevV = ex.uni(DV.nlev), nlevM = ex.uni(DM.nlev);
+        const DacSink sinkV{io + ex.uni(DV.by_off[0]), sh.bmV0, listV, &sh.nlistV, ex.uni(DV.n[0]), ex.uni(DV.n[1]), inst, kGuardVPos,
+                            io + ex.uni(DV.by_off[1]), sh.prefV};
+        const DacSink sinkM{io + ex.uni(DM.by_off[0]), sh.bmM[0], listM, &sh.nlistM, ex.uni(DM.n[0]), ex.uni(DM.n[1]), inst, kGuardMPos,
+                            io + ex.uni(DM.by_off[1]), sh.prefM};
 
         // 5b. plane 0 of both Dacs, T (and eqB) bits.  Pass A covers the nodes of heights >= 2; it is instantiated
         // per emission mode (EM_P1 repeats the walk only to place second bytes, so it skips the bitmaps and lists).
@@ -1405,7 +1455,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             guard_flush(ex);
         });
         };
-        const uint32_t nI2 = TT.Ni[2], nI1 = TT.Ni[1];
+        const uint32_t nI2 = ex.uni(TT.Ni[2]), nI1 = ex.uni(TT.Ni[1]);
         if (use_stash) {
             // ---- a Log whose values all fit two bytes, emitted from the stash in two passes (EM_P0, EM_P1) ----
             // one work item per I record: the four height-1 children of an internal height-2 node.  Records are in
@@ -1466,14 +1516,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             ex.stamp(6);
             // T, eqB and the continuation bitmaps of both Dacs (serialized; rank prefixes kept for the second bytes)
             {
-                const BmJob jobs[4] = {{sh.bmT, TT.LT, nullptr, io + 13},
-                                       {sh.bmE, TT.LT - TT.M0, nullptr, io + log_eq_off},
-                                       {sh.bmV0, DV.n[0], sh.prefV, DV.nlev > 0 ? io + DV.bm_off[0] : nullptr},
-                                       {sh.bmM[0], DM.n[0], sh.prefM, DM.nlev > 0 ? io + DM.bm_off[0] : nullptr}};
+                const uint32_t lt = ex.uni(TT.LT), m0 = ex.uni(TT.M0);
+                const BmJob jobs[4] = {{sh.bmT, lt, nullptr, io + 13},
+                                       {sh.bmE, lt - m0, nullptr, io + log_eq_off},
+                                       {sh.bmV0, sinkV.n0, sh.prefV, nlevV > 0 ? io + ex.uni(DV.bm_off[0]) : nullptr},
+                                       {sh.bmM[0], sinkM.n0, sh.prefM, nlevM > 0 ? io + ex.uni(DM.bm_off[0]) : nullptr}};
                 bitmaps_finish<C, 4>(ex, jobs);
             }
             ex.stamp(8);
-            if (DV.nlev > 1 || DM.nlev > 1) {
+            if (nlevV > 1 || nlevM > 1) {
                 // byte 1 of what pass A emitted, replayed from the registers it left behind
                 ex.par([&](int tid, EncRegs& r) {
                     auto put = [&](const DacSink& d, uint32_t* bm0, uint32_t pos, uint32_t hi) {
@@ -1510,8 +1561,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 ex.stamp(15);
                 passQ(P1{});
                 ex.stamp(16);
-                if (DV.nlev > 1) bitmap_write_zero<C>(ex, DV.n[1], io + DV.bm_off[1]);
-                if (DM.nlev > 1) bitmap_write_zero<C>(ex, DM.n[1], io + DM.bm_off[1]);
+                if (nlevV > 1) bitmap_write_zero<C>(ex, sinkV.n1, io + ex.uni(DV.bm_off[1]));
+                if (nlevM > 1) bitmap_write_zero<C>(ex, sinkM.n1, io + ex.uni(DM.bm_off[1]));
             }
             ex.stamp(9);
         } else {
@@ -1618,12 +1669,25 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             });
             ex.stamp(as_snapshot ? 5 : 6);  // plane-0 emission (5: snapshot, 6: log)
             // 5c. bitmaps + higher planes
-            bitmap_finish_write<C>(ex, sh.bmT, TT.LT, sh.prefM, io + 13);
-            if (!as_snapshot) bitmap_finish_write<C>(ex, sh.bmE, TT.LT - TT.M0, sh.prefM, io + log_eq_off);
+            bitmap_finish_write<C>(ex, sh.bmT, ex.uni(TT.LT), sh.prefM, io + 13);
+            if (!as_snapshot) bitmap_finish_write<C>(ex, sh.bmE, ex.uni(TT.LT) - ex.uni(TT.M0), sh.prefM, io + log_eq_off);
             ex.stamp(7);  // T / eqB bitmaps
-            dac_finish<C>(ex, DV, io, sh.bmV0, sh.bmV1(), sh.prefV, listV, &sh.nlistV);
+            auto uni_layout = [&](const DacLayout& L) {  // wave-uniform copy (dac_finish branches on it around barriers)
+                DacLayout U;
+#pragma unroll
+                for (int i = 0; i < 5; i++) U.n[i] = ex.uni(L.n[i]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    U.bm_off[i] = ex.uni(L.bm_off[i]);
+                    U.by_off[i] = ex.uni(L.by_off[i]);
+                }
+                U.nlev = ex.uni(L.nlev);
+                U.end = ex.uni(L.end);
+                return U;
+            };
+            dac_finish<C>(ex, uni_layout(DV), io, sh.bmV0, sh.bmV1(), sh.prefV, listV, &sh.nlistV);
             ex.stamp(8);  // Lmax Dac: bitmaps + planes >= 1
-            dac_finish<C>(ex, DM, io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
+            dac_finish<C>(ex, uni_layout(DM), io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
             ex.stamp(9);  // Lmin Dac: planes >= 1
         }
 
