@@ -1179,13 +1179,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             ex.par([&](int tid, EncRegs&) {
                 if (tid != 0) return;
                 auto& pl = sh.pl;
-                auto choose = [&](bool snap) {
+                // the decision: W = the winner's totals, size = its serialized size
+                auto choose = [&](bool snap, const Totals<C>& W, uint32_t size, uint32_t narrow) {
                     pl.as_snapshot = snap ? 1u : 0u;
-                    pl.isize = snap ? pl.M[0].end : pl.M[1].end;
+                    pl.isize = size;
                     // a Log is emitted from the stash when phase 1 managed to record all of it
-                    pl.use_stash = (!snap && pl.narrow && 5u * stI + 3u * stQ <= stash_cap && stI == pl.T[1].Ni[2] &&
-                                    stQ == pl.T[1].Ni[1]) ? 1u : 0u;
-                    const Totals<C>& W = pl.T[snap ? 0 : 1];
+                    pl.use_stash = (!snap && narrow && 5u * stI + 3u * stQ <= stash_cap && stI == W.Ni[2] && stQ == W.Ni[1]) ? 1u : 0u;
 #pragma unroll
                     for (int h = 0; h <= H; h++) {
                         sh.ttV[h] = W.offV[h];
@@ -1199,47 +1198,62 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         rr += W.Ni[h];
                     }
                     sh.ttR[H + 1] = rr;
-                    pl.need = 0;
                 };
                 if (stage == 1) {
-                    const uint32_t t0 = sh.tot[0], t1 = sh.tot[1], t2 = sh.tot[2];
-                    pl.T[0].from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);
-                    pl.need = 0;
-                    pl.narrow = 0;
-                    pl.log_size = 0;
-                    pl.eq_off = 0;
+                    // everything is computed in this lane's registers and stored once: a chain of LDS round trips
+                    // here would be paid by the 1023 threads waiting at the barrier
+                    const uint32_t t0 = sh.tot[0], t1 = sh.tot[1], t2 = sh.tot[2], t3 = sh.tot[3], t4 = sh.tot[4], t5 = sh.tot[5],
+                                   t6 = sh.tot[6];
+                    Totals<C> TS, TL;
+                    DacLayout LV{}, LM{};
+                    TS.from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);
+                    uint32_t need = 0, narrow = 0, log_size = 0, eq_off = 0;
                     if (have_s) {
-                        const uint32_t t3 = sh.tot[3], t4 = sh.tot[4], t5 = sh.tot[5], t6 = sh.tot[6];
-                        pl.T[1].from((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30), t4);
-                        pl.narrow = t6 == 0 ? 1u : 0u;
-                        pl.eq_off = 13 + bitmap_size(pl.T[1].LT);
-                        if (t6 == 0) {  // only "> 1 byte" counts are kept inline
-                            pl.V[1] = dac_layout(pl.eq_off + bitmap_size(pl.T[1].LT - pl.T[1].M0), pl.T[1].N0, t5 & 0x1ffffu, 0, 0);
-                            pl.M[1] = dac_layout(pl.V[1].end, pl.T[1].M0, t5 >> 17, 0, 0);
-                            pl.log_size = pl.M[1].end;  // log.rs:95-97
+                        TL.from((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30), t4);
+                        narrow = t6 == 0 ? 1u : 0u;
+                        eq_off = 13 + bitmap_size(TL.LT);
+                        if (narrow) {  // only "> 1 byte" counts are kept inline
+                            LV = dac_layout(eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, t5 & 0x1ffffu, 0, 0);
+                            LM = dac_layout(LV.end, TL.M0, t5 >> 17, 0, 0);
+                            log_size = LM.end;  // log.rs:95-97
                         } else {
-                            pl.need = 1;  // some log value may need 3+ bytes: count exactly first
+                            need = 1;  // some log value may need 3+ bytes: count exactly first
                         }
+                        pl.T[1] = TL;
+                        pl.V[1] = LV;
+                        pl.M[1] = LM;
                     }
-                    const uint32_t sbase = 13 + bitmap_size(pl.T[0].LT);
-                    pl.V[0] = dac_layout(sbase, pl.T[0].N0, 0, 0, 0);
-                    pl.M[0] = dac_layout(pl.V[0].end, pl.T[0].M0, 0, 0, 0);
-                    pl.snap_lb = pl.M[0].end;
-                    if (pl.need == 0) {
-                        if (!have_s || cap254 || pl.snap_lb <= pl.log_size) pl.need = 2;
-                        else choose(false);
+                    const uint32_t sbase = 13 + bitmap_size(TS.LT);
+                    const DacLayout SV = dac_layout(sbase, TS.N0, 0, 0, 0);
+                    const DacLayout SM = dac_layout(SV.end, TS.M0, 0, 0, 0);
+                    pl.T[0] = TS;
+                    pl.V[0] = SV;
+                    pl.M[0] = SM;
+                    pl.narrow = narrow;
+                    pl.log_size = log_size;
+                    pl.eq_off = eq_off;
+                    pl.snap_lb = SM.end;
+                    if (need == 0) {
+                        if (!have_s || cap254 || SM.end <= log_size) need = 2;
+                        else choose(false, TL, log_size, narrow);
                     }
+                    pl.need = need;
                 } else if (stage == 2) {  // exact classes of the log are in sh.tot[8..13]
                     pl.V[1] = dac_layout(pl.eq_off + bitmap_size(pl.T[1].LT - pl.T[1].M0), pl.T[1].N0, sh.tot[8], sh.tot[9], sh.tot[10]);
                     pl.M[1] = dac_layout(pl.V[1].end, pl.T[1].M0, sh.tot[11], sh.tot[12], sh.tot[13]);
                     pl.log_size = pl.M[1].end;
                     if (cap254 || pl.snap_lb <= pl.log_size) pl.need = 2;
-                    else choose(false);
+                    else {
+                        choose(false, pl.T[1], pl.log_size, pl.narrow);
+                        pl.need = 0;
+                    }
                 } else {  // exact classes of the snapshot are in sh.tot[8..13]
                     const uint32_t sbase = 13 + bitmap_size(pl.T[0].LT);
                     pl.V[0] = dac_layout(sbase, pl.T[0].N0, sh.tot[8], sh.tot[9], sh.tot[10]);
                     pl.M[0] = dac_layout(pl.V[0].end, pl.T[0].M0, sh.tot[11], sh.tot[12], sh.tot[13]);
-                    choose(!have_s || cap254 || pl.M[0].end <= pl.log_size);
+                    const bool snap = !have_s || cap254 || pl.M[0].end <= pl.log_size;
+                    choose(snap, pl.T[snap ? 0 : 1], snap ? pl.M[0].end : pl.log_size, pl.narrow);
+                    pl.need = 0;
                 }
             });
         };
