@@ -33,7 +33,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=1024, help="chunks per GPU (configs[1]: 1024)")
     ap.add_argument("--instants", type=int, default=32)
     ap.add_argument("--side", type=int, default=256)
-    ap.add_argument("--dtype", choices=["i32", "i64"], default="i32")
+    ap.add_argument("--dtype", choices=["i32", "i64", "f32"], default="i32",
+                    help="i32 (default): stored fixed-point integers; f32: floats converted on the fly (to_fixed, --fbits)")
+    ap.add_argument("--fbits", type=int, default=3, help="fractional bits of the f32 workload")
     ap.add_argument("--cpu-sample", type=int, default=24, help="chunks timed on the CPU oracle (0 = skip)")
     ap.add_argument("--verify", type=int, default=4, help="chunks compared byte-for-byte with the oracle (untimed)")
     ap.add_argument("--pad-elems", type=int, default=0, help="extra elements between consecutive chunks in HBM")
@@ -64,9 +66,9 @@ def main():
         raise RuntimeError("libdcdf_k2r.so sees no GPU; the MI355X path has no CPU fallback")
 
     n, T, S = args.chunks, args.instants, args.side
-    tdt = torch.int32 if args.dtype == "i32" else torch.int64
-    code = L.DCDF_I32 if args.dtype == "i32" else L.DCDF_I64
-    esz = 4 if args.dtype == "i32" else 8
+    tdt = {"i32": torch.int32, "i64": torch.int64, "f32": torch.int32}[args.dtype]
+    code = {"i32": L.DCDF_I32, "i64": L.DCDF_I64, "f32": L.DCDF_I32}[args.dtype]
+    esz = 8 if args.dtype == "i64" else 4
     per = T * S * S + args.pad_elems
     flat = torch.empty((n * per,), dtype=tdt, device="cuda")
     data = [flat[c * per:c * per + T * S * S].view(T, S, S) for c in range(n)]
@@ -74,8 +76,15 @@ def main():
     for c in range(n):
         synth_fill(data[c].data_ptr(), code, base_seed + c, 0, T, 0, S, 0, S)
     torch.cuda.synchronize()
+    fb = 0
+    if args.dtype == "f32":  # the same integers as exact multiples of 2^-fbits in float32 (|v| < 2^24)
+        fb = args.fbits
+        assert int(flat.abs().max().item()) < (1 << 24)
+        flat = flat.to(torch.float32) / float(1 << fb)
+        data = [flat[c * per:c * per + T * S * S].view(T, S, S) for c in range(n)]
+        code = L.DCDF_F32
 
-    descs = [(data[c].data_ptr(), code, (S * S, S, 1), (T, S, S)) for c in range(n)]
+    descs = [(data[c].data_ptr(), code, (S * S, S, 1), (T, S, S), fb, 0) for c in range(n)]
     enc = Encoder(descs, k=2)
     cells_per_step = n * T * S * S
 
@@ -112,7 +121,7 @@ def main():
         import oracle_lib as O
         for c in range(min(args.verify, n)):
             host = data[c].cpu().numpy()
-            assert enc.fetch(c) == O.chunk_build(host), "chunk %d: encoded bytes differ from the oracle" % c
+            assert enc.fetch(c) == O.chunk_build(host, fractional_bits=fb), "chunk %d: encoded bytes differ from the oracle" % c
             verified += 1
         if world == 1 and args.cpu_sample > 0:
             m = min(args.cpu_sample, n)
@@ -144,7 +153,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32" if args.dtype == "i32" else "int64",
+            "dtype": {"i32": "int32", "i64": "int64", "f32": "f32->fixed(int32 arithmetic)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d independent [%d,%d,%d] %s chunks per GPU, seed 0xDCDF0002+c" %
                                    (n, T, S, S, args.dtype),

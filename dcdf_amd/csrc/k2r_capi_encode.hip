@@ -86,9 +86,10 @@ static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls) {
     const uint32_t S = 1u << lg;
     cls->log2s = (int)lg;
     cls->padded = t.rows != S || t.cols != S;
-    cls->vec = !cls->padded && t.dtype == DCDF_I32 && t.stride_c == 1 && (t.stride_r % 4) == 0 && t.stride_r > 0 &&
-               (t.stride_t % 4) == 0 && ((uintptr_t)t.base % 16) == 0 &&
-               (uint64_t)(t.rows - 1) * (uint64_t)t.stride_r + t.cols < (1ull << 29);  // 32-bit byte offsets in the kernel
+    const bool rows16 = !cls->padded && t.stride_c == 1 && (t.stride_r % 4) == 0 && t.stride_r > 0 && (t.stride_t % 4) == 0 &&
+                        ((uintptr_t)t.base % 16) == 0 &&
+                        (uint64_t)(t.rows - 1) * (uint64_t)t.stride_r + t.cols < (1ull << 29);  // 32-bit byte offsets in the kernel
+    cls->vec = !rows16 ? 0 : (t.dtype == DCDF_I32 ? 1 : (t.dtype == DCDF_F32 ? 2 : 0));
     return DCDF_OK;
 }
 

@@ -186,48 +186,34 @@ K2R_HD int32_t narrow(int64_t v, int32_t& err) {
     return (int32_t)v;
 }
 
-// Loads the thread's 8x8 block of one instant (clamp-to-edge outside the tile when PADDED: a clamped
-// cell copies a valid cell of every partially valid ancestor, so min/max over all 64 registers equals
-// min/max over the valid cells; all-invalid nodes are recognised from geometry instead).
-template <bool PADDED, bool VEC>
-K2R_HD void load_block(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t c0, int32_t (&dst)[64], int32_t& err) {
-    if (VEC) {  // int32, unit column stride, 16-byte aligned rows, no padding
-        const int32_t* p = (const int32_t*)ta.base + (int64_t)inst * ta.st + (int64_t)r0 * ta.sr + c0;
-        uint32_t bad = 0;
+// Four float32 cells -> stored values (VEC == 2).  Fast path: a cell that is NaN, or whose scaled value is an
+// integer below 2^29 in magnitude, converts with a handful of VALU ops; anything else (fractions, huge values,
+// infinities, rounding requested) goes through to_fixed_dev, which reproduces fixed.rs:31-71 and its error kinds.
+K2R_HD void fixed4_f32(const float (&f)[4], const TileArgs& ta, float scale, int32_t (&v)[4], int32_t& err) {
+    bool all = ta.round == 0;
 #pragma unroll
-        for (int dr = 0; dr < 8; dr++) {
-            const int32_t* q = p + (int64_t)dr * ta.sr;
-            int32_t v[8];
-#if defined(__HIP_DEVICE_COMPILE__)
-            const int4 a = *(const int4*)q;
-            const int4 b = *(const int4*)(q + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-#else
-            for (int i = 0; i < 8; i++) v[i] = q[i];
-#endif
+    for (int i = 0; i < 4; i++) {
+        const float w = f[i] * scale;  // exact (power-of-two scale) unless it overflows to infinity
+        const bool isn = f[i] != f[i];
+        const bool ok = isn || (w == __builtin_truncf(w) && __builtin_fabsf(w) < 536870912.0f);
+        all = all && ok;
+        v[i] = (ok && !isn) ? (int32_t)w * 2 + 1 : 0;  // fixed.rs:70: (shifted << 1) | 1; NaN is stored as 0
+    }
+    if (!all) {
 #pragma unroll
-            for (int dc = 0; dc < 8; dc++) {
-                dst[cell_m(dr, dc)] = v[dc];
-                bad |= ((uint32_t)v[dc] + (uint32_t)VALUE_LIMIT) >> 31;
-            }
-        }
-        if (bad && err == 0) err = ERR_RANGE;
-    } else {
-#pragma unroll
-        for (int m = 0; m < 64; m++) {
-            uint32_t r = r0 + m_dr(m), c = c0 + m_dc(m);
-            if (PADDED) {
-                r = r < ta.rows ? r : ta.rows - 1;
-                c = c < ta.cols ? c : ta.cols - 1;
-            }
-            int64_t off = (int64_t)inst * ta.st + (int64_t)r * ta.sr + (int64_t)c * ta.sc;
-            dst[m] = narrow(load_stored(ta, off, err), err);
-        }
+        for (int i = 0; i < 4; i++) v[i] = narrow(to_fixed_dev<float>(f[i], ta.fbits, ta.round != 0, err), err);
     }
 }
+K2R_HD float as_f32(int32_t x) {
+    float f;
+    __builtin_memcpy(&f, &x, 4);
+    return f;
+}
+
 // 16 cells of height-2 node j (rows 4*(j>>1).., cols 4*(j&1)..) in local Morton order
-template <bool PADDED, bool VEC>
+// VEC: 0 = generic (any dtype / strides / padding), 1 = int32 rows loaded 16 bytes at a time, 2 = the same for float32
+// rows, converted to fixed point on the fly.
+template <bool PADDED, int VEC>
 K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t c0, int j, int32_t (&dst)[16],
                        int32_t& err) {
     const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
@@ -248,6 +234,10 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
 #else
             for (int i = 0; i < 4; i++) v[i] = ib[o + i];
 #endif
+            if (VEC == 2) {
+                const float f[4] = {as_f32(v[0]), as_f32(v[1]), as_f32(v[2]), as_f32(v[3])};
+                fixed4_f32(f, ta, (float)((int64_t)1 << ta.fbits), v, err);
+            }
 #pragma unroll
             for (int dc = 0; dc < 4; dc++) dst[cell_m(dr, dc)] = v[dc];
         }
@@ -274,7 +264,7 @@ K2R_HD void sched_fence() {
 }
 
 // the four cells of the 2x2 quad whose top-left cell is (rq,cq), row-major (== Morton) order
-template <bool PADDED, bool VEC>
+template <bool PADDED, int VEC>
 K2R_HD void load_quad(const TileArgs& ta, uint32_t inst, uint32_t rq, uint32_t cq, int32_t (&dst)[4], int32_t& err) {
     if (VEC) {
         const int32_t* ib = (const int32_t*)ta.base + (int64_t)inst * ta.st;
@@ -292,6 +282,10 @@ K2R_HD void load_quad(const TileArgs& ta, uint32_t inst, uint32_t rq, uint32_t c
             dst[2 * dr] = ib[o];
             dst[2 * dr + 1] = ib[o + 1];
 #endif
+        }
+        if (VEC == 2) {
+            const float f[4] = {as_f32(dst[0]), as_f32(dst[1]), as_f32(dst[2]), as_f32(dst[3])};
+            fixed4_f32(f, ta, (float)((int64_t)1 << ta.fbits), dst, err);
         }
     } else {
 #pragma unroll
@@ -742,16 +736,16 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
 }
 
 // ======================================================================================================
-// The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 input,
-// unit column stride, 16-byte aligned rows (=> vector loads), implies !PADDED.
+// The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 (1) or float32 (2)
+// input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
 // ======================================================================================================
-template <class C, bool PADDED, bool VEC, class EX>
+template <class C, bool PADDED, int VEC, class EX>
 K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM) {
     constexpr int H = C::H;
     constexpr int NT = C::NT;
     auto& sh = ex.sh;
     using SH = EncShared<C>;
-    static_assert(!(PADDED && VEC), "vector loads need an unpadded tile");
+    static_assert(!(PADDED && VEC != 0), "vector loads need an unpadded tile");
     // words of the LDS pool the stash may use (ta.stash_words: 0 = all of it; tests shrink it to force the fallback)
     const uint32_t stash_cap = (ta.stash_words != 0 && ta.stash_words < (uint32_t)SH::POOLW) ? ta.stash_words : (uint32_t)SH::POOLW;
 
@@ -924,6 +918,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             const int32_t mn3 = min4(r.mn2[0], r.mn2[1], r.mn2[2], r.mn2[3]);
             const int32_t mx3 = max4(r.mx2[0], r.mx2[1], r.mx2[2], r.mx2[3]);
             const bool P3S = !inv3 && mn3 != mx3;
+            // raw int32 rows are not range-checked cell by cell: the block's extremes decide (value-range contract)
+            if (VEC == 1 && (mn3 < -VALUE_LIMIT || mx3 >= VALUE_LIMIT) && err == 0) err = ERR_RANGE;
             sh.tmin[tid] = mn3;
             sh.tmax[tid] = mx3;
             // reduce words (completed in phase 3): [0] snapshot I1 | I2 << 16, [3] log I1 | I2 << 16,

@@ -1,5 +1,5 @@
 // k2r_encode_inst.hip -- ONE instantiation of the fused encoder kernel per translation unit
-// (compiled with -DK2R_L=<log2 sidelen> -DK2R_P=<0|1 padded> -DK2R_V=<0|1 vector loads>): the 18
+// (compiled with -DK2R_L=<log2 sidelen> -DK2R_P=<0|1 padded> -DK2R_V=<0|1|2 vector loads: none, int32, float32>): the 24
 // instantiations are large, fully unrolled kernels and build in parallel this way.
 #include <hip/hip_runtime.h>
 
@@ -12,7 +12,7 @@
 namespace k2r {
 
 // Persistent workgroups: each pops tile indices from a device work queue until it is empty.
-template <int LOG2S, bool PADDED, bool VEC>
+template <int LOG2S, bool PADDED, int VEC>
 __global__ void __launch_bounds__(EncCfg<LOG2S>::NT)
 k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, const uint32_t* __restrict__ order,
          uint32_t n, uint32_t* __restrict__ queue, uint64_t* __restrict__ lists) {
@@ -36,14 +36,14 @@ k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, c
 
 hipError_t K2R_CAT(launch_encode, K2R_L, K2R_P, K2R_V)(const EncodeLaunch& L, hipStream_t stream) {
     using C = EncCfg<K2R_L>;
-    hipLaunchKernelGGL((k_encode<K2R_L, (K2R_P != 0), (K2R_V != 0)>), dim3(L.grid), dim3(C::NT), 0, stream, L.tiles,
+    hipLaunchKernelGGL((k_encode<K2R_L, (K2R_P != 0), K2R_V>), dim3(L.grid), dim3(C::NT), 0, stream, L.tiles,
                        L.results, L.order, L.n, L.queue, L.lists);
     return hipGetLastError();
 }
 int K2R_CAT(occ_encode, K2R_L, K2R_P, K2R_V)() {
     using C = EncCfg<K2R_L>;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode<K2R_L, (K2R_P != 0), (K2R_V != 0)>, C::NT, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode<K2R_L, (K2R_P != 0), K2R_V>, C::NT, 0) !=
         hipSuccess)
         nb = 1;
     return nb < 1 ? 1 : nb;

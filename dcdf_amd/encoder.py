@@ -9,12 +9,15 @@ from . import _lib as L
 
 class Encoder:
     def __init__(self, descs, k=2, out_cap_per_tile=0):
-        """descs: list of (device_ptr, dtype_code, (st, sr, sc), (instants, rows, cols))"""
+        """descs: list of (device_ptr, dtype_code, (st, sr, sc), (instants, rows, cols)[, fractional_bits, round])"""
         n = len(descs)
         self.n = n
         self._descs = (L.TileDesc * n)()
-        for i, (ptr, dt, st, shp) in enumerate(descs):
+        for i, desc in enumerate(descs):
+            ptr, dt, st, shp = desc[:4]
             d = self._descs[i]
+            d.fractional_bits = desc[4] if len(desc) > 4 else 0
+            d.round = 1 if (len(desc) > 5 and desc[5]) else 0
             d.base = ptr
             d.dtype = dt
             d.stride_t, d.stride_r, d.stride_c = st

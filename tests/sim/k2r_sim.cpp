@@ -11,7 +11,7 @@
 
 using namespace k2r;
 
-template <int LOG2S, bool PADDED, bool VEC>
+template <int LOG2S, bool PADDED, int VEC>
 static void run(const TileArgs& ta, TileResult* res) {
     using C = EncCfg<LOG2S>;
     auto sh = std::make_unique<EncShared<C>>();
@@ -23,10 +23,11 @@ static void run(const TileArgs& ta, TileResult* res) {
 }
 
 template <int LOG2S>
-static void run_l(const TileArgs& ta, TileResult* res, bool padded, bool vec) {
-    if (padded) run<LOG2S, true, false>(ta, res);
-    else if (vec) run<LOG2S, false, true>(ta, res);
-    else run<LOG2S, false, false>(ta, res);
+static void run_l(const TileArgs& ta, TileResult* res, bool padded, int vec) {
+    if (padded) run<LOG2S, true, 0>(ta, res);
+    else if (vec == 1) run<LOG2S, false, 1>(ta, res);
+    else if (vec == 2) run<LOG2S, false, 2>(ta, res);
+    else run<LOG2S, false, 0>(ta, res);
 }
 
 static uint32_t g_last_stash_logs = 0;
@@ -48,8 +49,9 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
     if (lg < 3 || lg > 8 || instants == 0) return -8;
     const uint32_t S = 1u << lg;
     const bool padded = rows != S || cols != S;
-    const bool vec = !force_novec && !padded && dtype == ENC_I32 && sc == 1 && (sr % 4) == 0 && sr > 0 && (st % 4) == 0 &&
-                     ((uintptr_t)base % 16) == 0 && (uint64_t)(rows - 1) * (uint64_t)sr + cols < (1ull << 29);
+    const bool rows16 = !force_novec && !padded && sc == 1 && (sr % 4) == 0 && sr > 0 && (st % 4) == 0 && ((uintptr_t)base % 16) == 0 &&
+                        (uint64_t)(rows - 1) * (uint64_t)sr + cols < (1ull << 29);
+    const int vec = !rows16 ? 0 : (dtype == ENC_I32 ? 1 : (dtype == ENC_F32 ? 2 : 0));
     TileResult res{};
     switch (lg) {
         case 3: run_l<3>(ta, &res, padded, vec); break;

@@ -165,3 +165,33 @@ def test_adversarial_sets(dc):  # iid noise (every instant a snapshot
     noise = rng.integers(0, 2 ** 30 - 1, size=(6, 256, 256)).astype(np.int32)
     const = np.zeros((6, 256, 256), dtype=np.int32) + 1234
     assert_same(dc, [noise, const])
+
+
+def test_float32_full_size_chunks(dc):
+    """[32,256,256] float32 chunks (configs[1] as floats): aligned rows go through the converting 16-byte row loader."""
+    from dcdf_amd import synth
+    arrays = []
+    for c in range(2):
+        a = synth.cells(0xDCDF0002 + c, 0, 32, 0, 256, 0, 256, np.int32)
+        f = (a / 8.0).astype(np.float32)
+        f[5, 100, 7] = np.nan
+        arrays.append(f)
+    assert_same(dc, arrays, fractional_bits=3)
+    g = arrays[0][:6].copy()
+    g[2, 9, 9] = np.float32(5.0 + 1 / 64.0)
+    r = dc.build_batch([g], fractional_bits=3)[0]
+    assert isinstance(r, Exception) and r.code == -3
+    assert_same(dc, [g], fractional_bits=3, round=True)
+    g[2, 9, 9] = np.float32(3e8)
+    r = dc.build_batch([g], fractional_bits=3)[0]
+    assert isinstance(r, Exception) and r.code == -8
+
+
+def test_int32_rows_value_range_contract(dc):
+    a = np.zeros((2, 16, 16), dtype=np.int32)
+    a[1, 9, 9] = 2 ** 30
+    r = dc.build_batch([a])[0]
+    assert isinstance(r, Exception) and r.code == -8
+    a[1, 9, 9] = 2 ** 30 - 1
+    a[0, 1, 1] = -(2 ** 30)
+    assert_same(dc, [a])
