@@ -135,9 +135,10 @@ def main():
         k_ms = sum(kernel_ms) / len(kernel_ms)
         alg_bytes = cells_per_step * esz + out_bytes  # every input cell read once, every output byte written once
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = None  # HBM bytes per launch from the committed PMC passes -- only valid for the workload they were taken on
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tf):
+        default_workload = (n, T, S, args.dtype, args.pad_elems) == (1024, 32, 256, "i32", 0)
+        if default_workload and os.path.exists(tf):
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
@@ -161,7 +162,8 @@ def main():
                        "encoded_bytes_per_gpu": out_bytes, "snapshots": snaps, "bytes_verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k2r::k_encode<8,false,true>", "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes},
+                         "kernel": "k2r::k_encode<%d,false,%d>" % (S.bit_length() - 1, 2 if args.dtype == "f32" else (1 if args.dtype == "i32" else 0)),
+                         "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
