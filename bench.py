@@ -39,6 +39,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=24, help="chunks timed on the CPU oracle (0 = skip)")
     ap.add_argument("--verify", type=int, default=4, help="chunks compared byte-for-byte with the oracle (untimed)")
     ap.add_argument("--pad-elems", type=int, default=0, help="extra elements between consecutive chunks in HBM")
+    ap.add_argument("--workload", choices=["config1", "config2"], default="config1",
+                    help="config1 (default, the configuration the metric is quoted on): --chunks independent chunks per GPU; "
+                         "config2: the 4096x4096x365 raster (seed 0xDCDF0003) tiled into 16x16x12 chunks of <= 32 instants, "
+                         "sharded over the ranks by chunk")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,24 +73,48 @@ def main():
     tdt = {"i32": torch.int32, "i64": torch.int64, "f32": torch.int32}[args.dtype]
     code = {"i32": L.DCDF_I32, "i64": L.DCDF_I64, "f32": L.DCDF_I32}[args.dtype]
     esz = 8 if args.dtype == "i64" else 4
-    per = T * S * S + args.pad_elems
-    flat = torch.empty((n * per,), dtype=tdt, device="cuda")
-    data = [flat[c * per:c * per + T * S * S].view(T, S, S) for c in range(n)]
-    base_seed = 0xDCDF0002 + rank * n
-    for c in range(n):
-        synth_fill(data[c].data_ptr(), code, base_seed + c, 0, T, 0, S, 0, S)
-    torch.cuda.synchronize()
     fb = 0
+    if args.workload == "config1":
+        per = T * S * S + args.pad_elems
+        flat = torch.empty((n * per,), dtype=tdt, device="cuda")
+        data = [flat[c * per:c * per + T * S * S].view(T, S, S) for c in range(n)]
+        base_seed = 0xDCDF0002 + rank * n
+        for c in range(n):
+            synth_fill(data[c].data_ptr(), code, base_seed + c, 0, T, 0, S, 0, S)
+        workload = "configs[1]: %d independent [%d,%d,%d] %s chunks per GPU, seed 0xDCDF0002+c" % (n, T, S, S, args.dtype)
+    else:
+        # BASELINE configs[2]/[3]: one 4096x4096x365 raster; chunk (seg, i, j) = instants [32 seg, min(365, 32 seg + 32)) of
+        # rows [256 i, 256 i + 256), cols [256 j, 256 j + 256); the chunks are dealt to the ranks balanced by cell count (dcdf_amd/shard.py)
+        from dcdf_amd.shard import my_chunks, partition
+        S, T = 256, 32
+        grid = [(seg, i, j) for seg in range(12) for i in range(16) for j in range(16)]
+        owner = partition([(min(365, 32 * seg + 32) - 32 * seg) * S * S for seg, _, _ in grid], world)
+        mine = [grid[g] for g in my_chunks(owner, rank)]
+        n = len(mine)
+        sizes = [(min(365, 32 * seg + 32) - 32 * seg) * S * S for seg, _, _ in mine]
+        offs = [0]
+        for z in sizes:
+            offs.append(offs[-1] + z)
+        flat = torch.empty((offs[-1],), dtype=tdt, device="cuda")
+        data = []
+        for (seg, i, j), o, z in zip(mine, offs, sizes):
+            t0, t1 = 32 * seg, min(365, 32 * seg + 32)
+            v = flat[o:o + z].view(t1 - t0, S, S)
+            synth_fill(v.data_ptr(), code, 0xDCDF0003, t0, t1, S * i, S * i + S, S * j, S * j + S)
+            data.append(v)
+        workload = "configs[2]: 4096x4096x365 %s raster, seed 0xDCDF0003, %d of 3072 [<=32,256,256] chunks on this GPU" % (args.dtype, n)
+    torch.cuda.synchronize()
     if args.dtype == "f32":  # the same integers as exact multiples of 2^-fbits in float32 (|v| < 2^24)
         fb = args.fbits
         assert int(flat.abs().max().item()) < (1 << 24)
-        flat = flat.to(torch.float32) / float(1 << fb)
-        data = [flat[c * per:c * per + T * S * S].view(T, S, S) for c in range(n)]
+        flat2 = flat.to(torch.float32) / float(1 << fb)
+        data = [flat2[d.storage_offset():d.storage_offset() + d.numel()].view(d.shape) for d in data]
+        flat = flat2
         code = L.DCDF_F32
 
-    descs = [(data[c].data_ptr(), code, (S * S, S, 1), (T, S, S), fb, 0) for c in range(n)]
+    descs = [(d.data_ptr(), code, (S * S, S, 1), tuple(d.shape), fb, 0) for d in data]
     enc = Encoder(descs, k=2)
-    cells_per_step = n * T * S * S
+    cells_per_step = sum(d.numel() for d in data)
 
     def barrier():
         torch.cuda.synchronize()
@@ -125,9 +153,10 @@ def main():
             verified += 1
         if world == 1 and args.cpu_sample > 0:
             m = min(args.cpu_sample, n)
-            sample = torch.stack(data[:m]).cpu().numpy()
+            m = min(m, sum(1 for d in data if d.shape == data[0].shape))
+            sample = torch.stack([d for d in data if d.shape == data[0].shape][:m]).cpu().numpy()
             sec, tb, _ = O.bench_build(sample)
-            cpu = {"value": m * T * S * S / sec, "unit": "cells/s", "cores": 1, "kind": "port",
+            cpu = {"value": sample.size / sec, "unit": "cells/s", "cores": 1, "kind": "port",
                    "sample": "first %d of the %d [%d,%d,%d] %s chunks (%.1f s); C++ restatement of the Rust "
                              "reference, serial like superchunk.rs:166-188" % (m, n, T, S, S, args.dtype, sec)}
 
@@ -137,7 +166,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the committed PMC passes -- only valid for the workload they were taken on
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        default_workload = (n, T, S, args.dtype, args.pad_elems) == (1024, 32, 256, "i32", 0)
+        default_workload = (args.workload, n, T, S, args.dtype, args.pad_elems) == ("config1", 1024, 32, 256, "i32", 0)
         if default_workload and os.path.exists(tf):
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
@@ -156,8 +185,7 @@ def main():
             "vs_baseline": None,
             "dtype": {"i32": "int32", "i64": "int64", "f32": "f32->fixed(int32 arithmetic)"}[args.dtype],
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d independent [%d,%d,%d] %s chunks per GPU, seed 0xDCDF0002+c" %
-                                   (n, T, S, S, args.dtype),
+            "config": {"workload": workload,
                        "chunks_per_gpu": n, "k": 2, "device": name.decode(), "failed_tiles": bad,
                        "encoded_bytes_per_gpu": out_bytes, "snapshots": snaps, "bytes_verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
