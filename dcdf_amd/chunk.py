@@ -203,3 +203,16 @@ def window(data, t0, t1, r0, r1, c0, c1, dtype=None):
 
 def search(data, t0, t1, r0, r1, c0, c1, lower, upper):
     return Chunk(data).iter_search(Cube(t0, t1, r0, r1, c0, c1), lower, upper)
+
+
+def suggest_fraction(data):
+    """fixed.rs:96-159 (`suggest_fraction`, used per buffer by mmbuffer.rs:596-613): for a float32/float64 array
+    [instants, rows, cols] returns ("precise", bits) -- the fewest fractional bits that store every value exactly --
+    or ("round", bits) when even the widest shift leaves a fraction.  Computed on the GPU."""
+    a = np.asarray(data)
+    if a.ndim != 3 or a.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError("expected a 3-D float32/float64 array")
+    d = _desc(a, 0, False)
+    rnd, bits = C.c_int32(), C.c_int32()
+    L.check(L.lib().dcdf_suggest_fraction(C.byref(d), L.MEM_HOST, C.byref(rnd), C.byref(bits)), "suggest_fraction")
+    return ("round" if rnd.value else "precise", int(bits.value))

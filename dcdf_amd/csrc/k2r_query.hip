@@ -498,8 +498,3 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
     return DCDF_OK;
 }
 
-// fixed.rs:96-159 on the device is a "next" row of SURVEY 8(f); until then the entry point says so loudly.
-extern "C" int dcdf_suggest_fraction(const dcdf_tile_desc* tile, int mem, int32_t* out_round, int32_t* out_bits) {
-    (void)tile; (void)mem; (void)out_round; (void)out_bits;
-    return DCDF_ERR_UNSUPPORTED;
-}

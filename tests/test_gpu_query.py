@@ -188,3 +188,38 @@ def test_synthetic_256_roundtrip_and_batches(dc):
     for q, (s, e, t, bo, l, r) in enumerate(spec):
         got = set(map(tuple, res[int(soffs[q]):int(soffs[q] + counts[q])].tolist()))
         assert got == brute(a, s, e, t, bo, l, r, int(lower[q]), int(upper[q]))
+
+
+def test_suggest_fraction_golden_and_random(dc):  # fixed.rs:96-159, tests fixed.rs:311-401
+    import json, os
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+
+    def f(x):
+        return float("nan") if x == "nan" else x
+
+    for data, ft, rnd, bits in G["suggest_fraction"]:
+        dt = np.float32 if ft == "f32" else np.float64
+        if data == "fixed_array":
+            src = np.array([[[f(v) for v in row] for row in inst] for inst in G["fixed_array"]], dtype=np.float32)
+            arr = np.stack([src[i % 3] for i in range(100)])
+        else:
+            arr = np.array([f(x) for x in data], dtype=dt).reshape(1, 1, -1)
+        assert dc.suggest_fraction(arr) == ("round" if rnd else "precise", bits), (data, ft)
+    rng = np.random.default_rng(3)
+    for dt, ft in ((np.float32, "f32"), (np.float64, "f64")):
+        for bits in (0, 1, 5, 11):
+            a = (rng.integers(-5000, 5000, size=(7, 33, 20)) / float(1 << bits)).astype(dt)
+            a[rng.random(a.shape) < 0.05] = np.nan
+            want = O.suggest_fraction(a, ft)
+            assert dc.suggest_fraction(a) == ("round" if want[0] else "precise", want[1])
+            v = a[:, ::2, 1:15:3]  # strided view
+            want = O.suggest_fraction(np.ascontiguousarray(v), ft)
+            assert dc.suggest_fraction(v) == ("round" if want[0] else "precise", want[1])
+    a = np.full((2, 4, 4), 0.1, dtype=np.float64)
+    a[0, 0, 0] = 316.0  # fixed.rs:358-371: loss of precision -> Round(53)
+    assert dc.suggest_fraction(a) == ("round", 53)
+    assert dc.suggest_fraction(np.full((1, 2, 2), np.nan, dtype=np.float32)) == ("precise", 0)
+    assert dc.suggest_fraction(-np.ones((1, 2, 2), dtype=np.float32)) == (lambda w: ("round" if w[0] else "precise", w[1]))(
+        O.suggest_fraction(-np.ones((1, 2, 2), dtype=np.float32), "f32"))
+    with pytest.raises(dc.DcdfError):
+        dc.suggest_fraction(np.full((1, 1, 2), 1e300, dtype=np.float64))  # whole part needs more than 62 bits
