@@ -52,9 +52,15 @@ struct EncCfg {
 };
 
 struct EncRegs {
-    // summaries of the four height-2 nodes of this thread's 8x8 block, carried from analysis to emission
-    int32_t mn2[4], mx2[4], smn2[4], smx2[4];
-    uint32_t flags;  // bit j: eq2[j] (all cells of node j differ from the snapshot by one constant)
+    // What emission needs to know about the four height-2 nodes of this thread's 8x8 block, carried from analysis:
+    // the log candidate's values as int16 pairs (Lmax | Lmin << 16; meaningful when the log is "narrow") and flag
+    // bits.  The snapshot candidate's values (and those of wide logs) are recomputed from the tile by the passes
+    // that emit them -- 1 instant in 32 -- because 16 more live registers across phase 1 meant spills, and a spill
+    // reload behind global stores waits for those stores (s_waitcnt vmcnt counts both on gfx9).
+    uint32_t d2[4];
+    uint32_t flags;  // bits 0-3: eq2[j] (all cells of node j differ from the snapshot by one constant); 4-27: internal
+                     // quads per node (snapshot, log); 28: wide; bits 29-31 unused
+    uint32_t u2;     // bit j: node j is uniform (or entirely outside the tile)
     uint32_t sc[MAX_SCAN_FIELDS];  // words handed to ex.scan<>/ex.reduce<> (layout: see phase 3)
     uint64_t pf_lo;                // saved exclusive prefix of the chosen candidate's lo pack
     uint32_t pa[9];                // what pass A emitted (positions, second bytes), replayed by the byte-1 pass
@@ -253,6 +259,17 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
             dst[m] = narrow(load_stored(ta, off, err), err);
         }
     }
+}
+
+// Returns v, but opaque to the optimizer.  Everything derived from the thread index alone (block origin, the top
+// node a thread looks after, bit positions...) is invariant across instants AND chunks; LICM hoists it to the
+// kernel prologue, where under the 128-VGPR cap it is spilled, to be reloaded from scratch in every instant -- behind
+// global stores the reload has to wait for.  Recomputing a few integer ops per phase is far cheaper.
+K2R_HD uint32_t opaque(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
 }
 
 // Keeps the instruction scheduler from hoisting the next sub-block's loads above the current sub-block's
@@ -814,8 +831,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0;
             Cls lMax, lMin;
             Cls lPend2;  // "> 1 byte" counts of the four height-2 log Lmax values, valid iff PL3
-            int32_t df2[4];
-            uint32_t eqbits = 0, eqall = 1, cntbits = 0, wide = 0;
+            int32_t df2_0 = 0, mn3 = 0, mx3 = 0, smn3 = 0, smx3 = 0;
+            uint32_t eqbits = 0, eqall = 1, cntbits = 0, wide = 0, u2 = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 sched_fence();
@@ -836,8 +853,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 }
                 const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
                 const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
-                r.mn2[j] = mn2;
-                r.mx2[j] = mx2;
+                mn3 = j == 0 ? mn2 : (mn2 < mn3 ? mn2 : mn3);
+                mx3 = j == 0 ? mx2 : (mx2 > mx3 ? mx2 : mx3);
+                u2 |= ((inv2 || mn2 == mx2) ? 1u : 0u) << j;
                 const bool P2S = !inv2 && mn2 != mx2;
                 sI2 += P2S ? 1u : 0u;
                 // (the snapshot candidate's byte classes are computed lazily: see classes_pass below)
@@ -892,7 +910,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const int32_t smx2 = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
                     const bool eq2 = eq1[0] && eq1[1] && eq1[2] && eq1[3] && df1[0] == df1[1] && df1[0] == df1[2] &&
                                      df1[0] == df1[3];
-                    df2[j] = df1[0];
+                    if (j == 0) df2_0 = df1[0];
+                    eqall &= df1[0] == df2_0 ? 1u : 0u;
                     const bool P2L = !inv2 && mn2 != mx2 && !eq2;
                     if (P2L) {  // I record: owner, ordinals, T / eqB runs and the Lmax|Lmin pairs of the four quads
                         const uint32_t k = ex.lds_add(&sh.stI, 1u);
@@ -909,14 +928,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     lMax.add(pend1, P2L);
                     lPend2.add1(inv2 ? 0 : mx2 - smx2, true);
                     lMin.add1(mn2 - smn2, P2L);
-                    r.smn2[j] = smn2;
-                    r.smx2[j] = smx2;
+                    smn3 = j == 0 ? smn2 : (smn2 < smn3 ? smn2 : smn3);
+                    smx3 = j == 0 ? smx2 : (smx2 > smx3 ? smx2 : smx3);
+                    r.d2[j] = ((uint32_t)(inv2 ? 0 : mx2 - smx2) & 0xffffu) | ((uint32_t)(mn2 - smn2) << 16);  // log.rs:133,148
                     eqbits |= (eq2 ? 1u : 0u) << j;
                     eqall &= eq2 ? 1u : 0u;
                 }
             }
-            const int32_t mn3 = min4(r.mn2[0], r.mn2[1], r.mn2[2], r.mn2[3]);
-            const int32_t mx3 = max4(r.mx2[0], r.mx2[1], r.mx2[2], r.mx2[3]);
             const bool P3S = !inv3 && mn3 != mx3;
             // raw int32 rows are not range-checked cell by cell: the block's extremes decide (value-range contract)
             if (VEC == 1 && (mn3 < -VALUE_LIMIT || mx3 >= VALUE_LIMIT) && err == 0) err = ERR_RANGE;
@@ -927,9 +945,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[0] = sI1 | (sI2 << 16);
             (void)P3S;
             if (have_s) {
-                const int32_t smn3 = min4(r.smn2[0], r.smn2[1], r.smn2[2], r.smn2[3]);
-                const int32_t smx3 = max4(r.smx2[0], r.smx2[1], r.smx2[2], r.smx2[3]);
-                const bool eq3 = eqall && df2[0] == df2[1] && df2[0] == df2[2] && df2[0] == df2[3];
+                const bool eq3 = eqall != 0;
                 const bool PL3 = !inv3 && mn3 != mx3 && !eq3;
                 lMax.add(lPend2, PL3);
                 // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: below 2^15 in magnitude none of them
@@ -938,10 +954,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 wide = (lo_b < -32768 || hi_b > 32767) ? 1u : 0u;
                 sh.smin[tid] = smn3;
                 sh.smax[tid] = smx3;
-                sh.diff[tid] = df2[0];
+                sh.diff[tid] = df2_0;
                 sh.eq[tid] = eq3 ? 1u : 0u;
             }
             r.flags = eqbits | cntbits | (wide << 28);
+            r.u2 = u2;
             if (tid < C::TBW) {
                 sh.tbS[tid] = 0;
                 sh.tbL[tid] = 0;
@@ -1053,15 +1070,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                 }
             };
-            node(3, (uint32_t)tid);
+            const uint32_t wt = opaque((uint32_t)tid);
+            node(3, wt);
             if (tid == 0) {
                 sh.stI = 0;
                 sh.stQ = 0;
             }
-            if (tid < C::NTOPX) {
+            if (wt < (uint32_t)C::NTOPX) {
                 int h;
                 uint32_t j;
-                top_decode((uint32_t)tid, h, j);
+                top_decode(wt, h, j);
                 node(h, j);
             }
             // reduce words: [0] snapshot I1 | I2 << 16   [1] snapshot I3 | log I3 << 16   [2] snapshot top pack
@@ -1112,7 +1130,23 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 for (int j = 0; j < 4; j++) {
                     const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
                     const bool inv2 = inval(rj, cj);
-                    const int32_t mn2 = sel4(r.mn2, j), mx2 = sel4(r.mx2, j);
+                    int32_t t16[16], s16[16];
+                    load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
+                    if (which != 0) load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);
+                    int32_t mn2 = t16[0], mx2 = t16[0], smn2 = 0, smx2 = 0;
+#pragma unroll
+                    for (int i = 1; i < 16; i++) {
+                        mn2 = t16[i] < mn2 ? t16[i] : mn2;
+                        mx2 = t16[i] > mx2 ? t16[i] : mx2;
+                    }
+                    if (which != 0) {
+                        smn2 = smx2 = s16[0];
+#pragma unroll
+                        for (int i = 1; i < 16; i++) {
+                            smn2 = s16[i] < smn2 ? s16[i] : smn2;
+                            smx2 = s16[i] > smx2 ? s16[i] : smx2;
+                        }
+                    }
                     const bool unif2 = inv2 || mn2 == mx2;
                     bool P2;
                     if (which == 0) {
@@ -1121,13 +1155,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         vMin.add(zz32(mn2 - mn3), P2);
                     } else {
                         P2 = !unif2 && ((r.flags >> j) & 1u) == 0;
-                        vMax.add(zz32(inv2 ? 0 : mx2 - sel4(r.smx2, j)), P3);
-                        vMin.add(zz32(mn2 - sel4(r.smn2, j)), P2);
+                        vMax.add(zz32(inv2 ? 0 : mx2 - smx2), P3);
+                        vMin.add(zz32(mn2 - smn2), P2);
                     }
                     if (!P2) continue;
-                    int32_t t16[16], s16[16];
-                    load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
-                    if (which != 0) load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
@@ -1395,19 +1426,14 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     if (e) bm_set(ex, sh.bmE, guard_pos(ex, sh.ttZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
                 }
             };
-            enode(3, (uint32_t)tid, 0);
-#ifdef K2R_X_STAMPS
-            ex.stamp(17);
-#endif
-            if (tid < C::NTOPX) {
+            const uint32_t wt = opaque((uint32_t)tid);
+            enode(3, wt, 0);
+            if (wt < (uint32_t)C::NTOPX) {
                 int h;
                 uint32_t j;
-                top_decode((uint32_t)tid, h, j);
+                top_decode(wt, h, j);
                 enode(h, j, 1);
             }
-#ifdef K2R_X_STAMPS
-            ex.stamp(18);
-#endif
 
             // -- the four height-2 children of this thread's block + the work list of internal height-2 nodes --
             const int32_t mn3 = sh.tmin[tid], mx3 = sh.tmax[tid];
@@ -1421,15 +1447,44 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const bool inv2 = inval(r0 + 4 * (j >> 1), c0 + 4 * (j & 1));
-                    const bool unif2 = inv2 || r.mn2[j] == r.mx2[j];
+                    const bool unif2 = ((r.u2 >> j) & 1u) != 0;
+                    int32_t vx, vn;  // the node's Lmax / Lmin values
+                    if (MODE == EM_LIST) {  // snapshots and wide logs: from the tile again (see EncRegs)
+                        int32_t lerr = 0, t16[16];
+                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
+                        int32_t mn2 = t16[0], mx2 = t16[0];
+#pragma unroll
+                        for (int i = 1; i < 16; i++) {
+                            mn2 = t16[i] < mn2 ? t16[i] : mn2;
+                            mx2 = t16[i] > mx2 ? t16[i] : mx2;
+                        }
+                        if (as_snapshot) {
+                            vx = inv2 ? mx3 : mx3 - mx2;  // snapshot.rs:139
+                            vn = mn2 - mn3;               // snapshot.rs:140
+                        } else {
+                            int32_t s16[16];
+                            load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, lerr);
+                            int32_t smn2 = s16[0], smx2 = s16[0];
+#pragma unroll
+                            for (int i = 1; i < 16; i++) {
+                                smn2 = s16[i] < smn2 ? s16[i] : smn2;
+                                smx2 = s16[i] > smx2 ? s16[i] : smx2;
+                            }
+                            vx = inv2 ? 0 : mx2 - smx2;  // log.rs:133
+                            vn = mn2 - smn2;             // log.rs:148
+                        }
+                    } else {  // narrow log: the int16 pair phase 1 kept
+                        vx = (int32_t)(int16_t)(r.d2[j] & 0xffffu);
+                        vn = (int32_t)r.d2[j] >> 16;
+                    }
                     if (as_snapshot) {
                         P2[j] = !unif2;
-                        z2v[j] = zz32(inv2 ? mx3 : mx3 - r.mx2[j]);   // snapshot.rs:139
-                        zm2[j] = zz32(r.mn2[j] - mn3);                 // snapshot.rs:140
+                        z2v[j] = zz32(vx);
+                        zm2[j] = zz32(vn);
                     } else {
                         P2[j] = !unif2 && ((r.flags >> j) & 1u) == 0;
-                        z2v[j] = zz32(inv2 ? 0 : r.mx2[j] - r.smx2[j]);  // log.rs:133
-                        zm2[j] = zz32(r.mn2[j] - r.smn2[j]);             // log.rs:148
+                        z2v[j] = zz32(vx);
+                        zm2[j] = zz32(vn);
                         if (!P2[j]) {  // T = 0: one eqB bit, set iff "equal" (log.rs:137-144)
                             erun = (erun << 1) | (unif2 ? 0u : 1u);
                             elen++;
@@ -1459,9 +1514,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                 }
             }
-#ifdef K2R_X_STAMPS
-            ex.stamp(19);
-#endif
             guard_flush(ex);
         });
         };
