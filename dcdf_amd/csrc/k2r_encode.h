@@ -63,7 +63,8 @@ struct EncRegs {
     uint32_t u2;     // bit j: node j is uniform (or entirely outside the tile)
     uint32_t sc[MAX_SCAN_FIELDS];  // words handed to ex.scan<>/ex.reduce<> (layout: see phase 3)
     uint64_t pf_lo;                // saved exclusive prefix of the chosen candidate's lo pack
-    uint32_t pa[9];                // what pass A emitted (positions, second bytes), replayed by the byte-1 pass
+    uint32_t pf_l2;                // second bytes before this block's height-2 group (Lmax | Lmin << 16)
+    uint32_t pa[5];                // what pass A emitted for nodes of heights >= 3 (positions, second bytes), replayed later
 };
 
 // ---- packed scan fields ------------------------------------------------------------------
@@ -403,6 +404,7 @@ struct InstPlan {
     uint32_t narrow;      // every log value fits 16 bits
     uint32_t log_size, snap_lb, eq_off;
     uint32_t as_snapshot, use_stash, isize;
+    uint32_t lngV[3], lngM[3];  // log: index (among second bytes) of the first one of heights 0..2
 };
 
 template <class C>
@@ -422,16 +424,21 @@ struct EncShared {
     //      from word POOLW) -- so that emitting a Log touches no input memory at all.
     //  (2) plane-0 emission of a Snapshot, or of a Log whose stash overflowed / whose values do not fit 16 bits:
     //      the work lists L2 (internal height-2 nodes) and L1 (internal quads) of the re-reading passes.
-    //  (3) Dac finishing in list mode: the second continuation bitmap of the Lmax Dac.
+    //  (3) Dac finishing in list mode: the second continuation bitmap and the rank prefixes of the Lmax Dac.
     static constexpr int POOL_L1 = 4 * C::NBLK;                 // word offset of L1 (16*NBLK u16 = 8*NBLK words)
     static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
-    static constexpr int POOLW = POOL_BMV1 + C::WV + 1 + (C::H == 8 ? 7000 : 0);  // sidelen 256: LDS filled to 160 KB
+    static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
+    static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? 4900 : 0);  // sidelen 256: LDS filled to 160 KB
     uint32_t pool[POOLW];
     K2R_HD uint32_t* L2() { return pool; }                                  // key = blk<<2|j | (quads before) << 12
     K2R_HD uint16_t* L1() { return (uint16_t*)(pool + POOL_L1); }           // key = blk<<4|j<<2|qq
     K2R_HD uint32_t* bmV1() { return pool + POOL_BMV1; }
-    uint32_t prefV[C::WV + 2];  // per-word rank prefixes of the Lmax Dac's continuation bitmap
-    uint32_t pfx[C::NBLK];  // per-thread exclusive prefix of the winner's lo pack (I1 | I2 << 16), for stash emission
+    K2R_HD uint32_t* prefV() { return pool + POOL_PREFV; }  // list mode: per-word rank prefixes of the Lmax Dac's plane 0
+    static constexpr int PREFTOP = 48;  // words of a continuation bitmap that can hold values of heights >= 3 (<= 1365 of them)
+    uint32_t prefTopV[PREFTOP + 1];     // EM_ONE mode: rank prefixes of those words only
+    // per-thread exclusive prefixes for stash emission (records find their owner's): [0] I1 | I2 << 16 of the winner,
+    // [1] second bytes of cell values, [2] second bytes of height-1 values: Lmax | Lmin << 16
+    uint32_t pfx[3][C::NBLK];
     uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
     uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
     uint32_t tbP[C::TBW + 1];           // per-word exclusive popcount prefix of the winner's flags
@@ -554,6 +561,7 @@ struct BmJob {
     const uint32_t* bm;  // LDS words
     uint32_t nbits;
     uint32_t* pref;      // LDS, may be null
+    uint32_t prefcap;    // prefixes are kept for words [0, prefcap) only
     uint8_t* dst;        // where the serialized BitMap goes; null = bitmap absent
 };
 template <class C, int NB, class EX>
@@ -586,12 +594,12 @@ K2R_HD void bitmaps_finish(EX& ex, const BmJob (&J)[NB]) {
             uint32_t run = r.sc[f];
             for (uint32_t w = w0; w < w0 + CH && w < W; w++) {
                 const uint32_t x = J[f].bm[w];
-                if (J[f].pref) J[f].pref[w] = run;
+                if (J[f].pref && w < J[f].prefcap) J[f].pref[w] = run;
                 run += popc32(x);
                 gstore32u(wd + 4 * w, __builtin_bswap32(x));
                 if ((w & 3u) == 3u && (w >> 2) < nidx) gstore32u(dst + 8 + 4 * (w >> 2), __builtin_bswap32(run));
             }
-            if (J[f].pref && w0 < W && w0 + CH >= W) J[f].pref[W] = run;  // total, for rank(len)
+            if (J[f].pref && w0 < W && w0 + CH >= W && W < J[f].prefcap) J[f].pref[W] = run;  // total, for rank(len)
         }
     });
 }
@@ -617,7 +625,11 @@ struct DacSink {
 //             < 2^16 after zig-zag).  EM_P0 stores the plane-0 bytes and sets the continuation bits; once the
 //             bitmap's rank prefixes exist, EM_P1 revisits the sources and stores byte 1 of every long value at
 //             rank1(continuation, pos) -- the decoder's own hop (dac.rs:83-90) -- with no list and no atomics.
-enum : int { EM_LIST = 0, EM_P0 = 1, EM_P1 = 2 };
+//             Used for the few nodes of heights >= 3.
+//   EM_ONE  : one pass, for the same two-plane Dacs, when the caller already knows `lpos` = that rank (phase 1
+//             counted the long values per level and a scan turned the counts into positions): plane-0 bytes,
+//             continuation bits and second bytes are all stored at once.
+enum : int { EM_LIST = 0, EM_P0 = 1, EM_P1 = 2, EM_ONE = 3 };
 template <int V>
 struct EmTag {
     static constexpr int value = V;
@@ -642,7 +654,7 @@ K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
 }
 // WHICH = 0: Lmax Dac (sh.bmV0, sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
 template <int WHICH, int MODE = EM_LIST, class EX>
-K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid) {
+K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid, uint32_t lpos = 0) {
     pos = guard_pos(ex, pos, 1, d.n0, d.code);
     uint32_t* const bm0 = WHICH ? ex.sh.bmM[0] : ex.sh.bmV0;
     if (MODE == EM_P1) {
@@ -659,13 +671,15 @@ K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int ti
             const uint32_t slot = ex.lds_add(WHICH ? &ex.sh.nlistM : &ex.sh.nlistV, 1u);
             d.list[guard_pos(ex, slot, 1, d.n1, d.code + 1)] = ((uint64_t)pos << 32) | (uint64_t)(zz >> 8);
         }
+        if (MODE == EM_ONE) gstore8(d.plane1 + guard_pos(ex, lpos, 1, d.n1, d.code + 1), (uint8_t)(zz >> 8));
     }
 }
 
 // Four values at consecutive positions pos..pos+3 (the children of one internal node are always adjacent in
 // level order): one unaligned 4-byte store of the plane-0 bytes; values longer than a byte take the slow path.
 template <int WHICH, int MODE = EM_LIST, class EX>
-K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3, int tid) {
+K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3, int tid,
+                  uint32_t lpos = 0) {
     pos = guard_pos(ex, pos, 4, d.n0, d.code);
     uint32_t* const bm0 = WHICH ? ex.sh.bmM[0] : ex.sh.bmV0;
     if (MODE == EM_P1) {
@@ -684,9 +698,19 @@ K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t 
     }
     gstore32u(d.plane0 + pos, (z0 & 0xffu) | ((z1 & 0xffu) << 8) | ((z2 & 0xffu) << 16) | (z3 << 24));
     if ((z0 | z1 | z2 | z3) > 0xffu) {
-        if (MODE == EM_P0) {
+        if (MODE == EM_P0 || MODE == EM_ONE) {
             const uint32_t run = (z0 > 0xffu ? 8u : 0u) | (z1 > 0xffu ? 4u : 0u) | (z2 > 0xffu ? 2u : 0u) | (z3 > 0xffu ? 1u : 0u);
             bm_or_run(ex, bm0, pos, 4, run);
+            if (MODE == EM_ONE) {
+                const uint32_t z[4] = {z0, z1, z2, z3};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (z[i] > 0xffu) {
+                        gstore8(d.plane1 + guard_pos(ex, lpos, 1, d.n1, d.code + 1), (uint8_t)(z[i] >> 8));
+                        lpos++;
+                    }
+                }
+            }
         } else {
             const uint32_t z[4] = {z0, z1, z2, z3};
 #pragma unroll
@@ -829,8 +853,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             int32_t err = 0;
             const bool inv3 = inval(r0, c0);
             uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0;
-            Cls lMax, lMin;
-            Cls lPend2;  // "> 1 byte" counts of the four height-2 log Lmax values, valid iff PL3
+            // Log values of this block needing a second byte, per level, packed in one register (the phase is register-
+            // bound): cL0 @0 (7b) cells, cL1 @7 (5b) / cL2 via pend2 @12 (3b) height-1 / height-2 Lmax values, mL1 @15 (5b) /
+            // mL2 @20 (3b) height-1 / height-2 Lmin values, pend1 @23 (3b).  pend* are counted before it is known whether
+            // their parent is internal.  The running values double as the place of a stash record's second bytes among
+            // its owner's (EM_ONE emission).
+            uint32_t lc = 0, cL2 = 0;
+            auto lng = [](int32_t v) -> uint32_t { return ((uint32_t)v + 128u) > 255u ? 1u : 0u; };  // zig-zag(v) > 0xff
             int32_t df2_0 = 0, mn3 = 0, mx3 = 0, smn3 = 0, smx3 = 0;
             uint32_t eqbits = 0, eqall = 1, cntbits = 0, wide = 0, u2 = 0;
 #pragma unroll
@@ -865,9 +894,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
                     int32_t smn1[4], smx1[4], df1[4];
                     bool eq1[4];
-                    Cls pend1;  // classes of the four height-1 Lmax values, valid iff P2L
-                    uint32_t recw[4], tb1 = 0, erun = 0, elen = 0;  // the I record of this node (see EncShared::pool)
-                    const uint32_t pre1 = lI1;
+                    uint32_t recw[4], tb1 = 0, erun = 0;  // the I record of this node (see EncShared::pool)
+                    const uint32_t pre1 = lI1, lc0 = lc;
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
@@ -888,23 +916,20 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         tb1 = (tb1 << 1) | (P1L ? 1u : 0u);
                         if (!P1L) {  // T = 0: one eqB bit, set iff "equal" rather than uniform (log.rs:137-144)
                             erun = (erun << 1) | ((inv1[qq] || mn1[qq] == mx1[qq]) ? 0u : 1u);
-                            elen++;
                         }
                         if (P1L) {  // Q record: owner, ordinal among the owner's internal quads, the four cell diffs
                             const uint32_t m = ex.lds_add(&sh.stQ, 1u);
                             if (3u * (m + 1u) <= stash_cap) {
                                 uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
-                                q[0] = (uint32_t)tid | (lI1 << 10);
+                                q[0] = (uint32_t)tid | (lI1 << 10) | ((lc & 127u) << 14);
                                 q[1] = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16);
                                 q[2] = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
                             }
                         }
                         lI1 += P1L ? 1u : 0u;
                         cntbits += (P1L ? 1u : 0u) << (16 + 3 * j);  // bits 16..27: internal quads per j, log
-#pragma unroll
-                        for (int i = 0; i < 4; i++) lMax.add1(d[i], P1L);            // cells: t - s
-                        pend1.add1(vx1, true);
-                        lMin.add1(vn1, P1L);
+                        lc += P1L ? lng(d[0]) + lng(d[1]) + lng(d[2]) + lng(d[3]) + (lng(vn1) << 15) : 0u;  // cells: t - s; Lmin
+                        lc += lng(vx1) << 23;
                     }
                     const int32_t smn2 = min4(smn1[0], smn1[1], smn1[2], smn1[3]);
                     const int32_t smx2 = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
@@ -917,7 +942,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         const uint32_t k = ex.lds_add(&sh.stI, 1u);
                         if (5u * (k + 1u) <= stash_cap) {
                             uint32_t* p = sh.pool + 5u * k;
-                            p[0] = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (tb1 << 16) | (erun << 20) | (elen << 24);
+                            p[0] = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (tb1 << 16) | (erun << 20) | (((lc >> 7) & 31u) << 24) |
+                                   (((lc0 >> 15) & 31u) << 28);
                             p[1] = recw[0];
                             p[2] = recw[1];
                             p[3] = recw[2];
@@ -925,9 +951,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         }
                     }
                     lI2 += P2L ? 1u : 0u;
-                    lMax.add(pend1, P2L);
-                    lPend2.add1(inv2 ? 0 : mx2 - smx2, true);
-                    lMin.add1(mn2 - smn2, P2L);
+                    lc += P2L ? (((lc >> 23) & 7u) << 7) + (lng(mn2 - smn2) << 20) : 0u;
+                    lc = (lc & 0x7fffffu) + (lng(inv2 ? 0 : mx2 - smx2) << 12);  // pend1 starts over
                     smn3 = j == 0 ? smn2 : (smn2 < smn3 ? smn2 : smn3);
                     smx3 = j == 0 ? smx2 : (smx2 > smx3 ? smx2 : smx3);
                     r.d2[j] = ((uint32_t)(inv2 ? 0 : mx2 - smx2) & 0xffffu) | ((uint32_t)(mn2 - smn2) << 16);  // log.rs:133,148
@@ -941,13 +966,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             sh.tmin[tid] = mn3;
             sh.tmax[tid] = mx3;
             // reduce words (completed in phase 3): [0] snapshot I1 | I2 << 16, [3] log I1 | I2 << 16,
-            //                                      [5] log c1(max) | c1(min) << 17
+            //                                      [7] cL0, [8] cL1 | cL2 << 16, [9] mL1 | mL2 << 16
             r.sc[0] = sI1 | (sI2 << 16);
             (void)P3S;
             if (have_s) {
                 const bool eq3 = eqall != 0;
                 const bool PL3 = !inv3 && mn3 != mx3 && !eq3;
-                lMax.add(lPend2, PL3);
+                cL2 = PL3 ? (lc >> 12) & 7u : 0u;
                 // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: below 2^15 in magnitude none of them
                 // needs a third byte; otherwise the exact classes_pass is requested (bit 60 of the top pack)
                 const int32_t lo_b = mn3 - smx3, hi_b = mx3 - smn3;
@@ -964,7 +989,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.tbL[tid] = 0;
             }
             r.sc[3] = lI1 | (lI2 << 16);
-            r.sc[5] = lMax.c1 | (lMin.c1 << 17);
+            r.sc[7] = lc & 127u;
+            r.sc[8] = ((lc >> 7) & 31u) | (cL2 << 16);
+            r.sc[9] = ((lc >> 15) & 31u) | (((lc >> 20) & 7u) << 16);
             if (err != 0) ex.lds_min(&sh.err, err);
         });
         const int32_t perr = ex.uni(sh.err);
@@ -1083,21 +1110,22 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 node(h, j);
             }
             // reduce words: [0] snapshot I1 | I2 << 16   [1] snapshot I3 | log I3 << 16   [2] snapshot top pack
-            //               [3] log I1 | I2 << 16        [4] log top pack                 [5] log c1(max) | c1(min) << 17
-            //               [6] "wide" requests
+            //               [3] log I1 | I2 << 16        [4] log top pack
+            //               [5] long log values at heights >= 3: Lmax | Lmin << 16      [6] "wide" requests
+            //               [7] cL0    [8] cL1 | cL2 << 16    [9] mL1 | mL2 << 16      (phase 1)
             r.sc[1] = sI3 | (lI3 << 16);
             r.sc[2] = sTop;
             r.sc[4] = lTop;
-            r.sc[5] += lMax.c1 + (lMin.c1 << 17);
+            r.sc[5] = lMax.c1 | (lMin.c1 << 16);
             r.sc[6] = wide;
         });
         ex.stamp(2);  // phase 3: own/top nodes
-        ex.template reduce<7>();
+        ex.template reduce<10>();
         ex.stamp(3);  // totals of the 4 packed fields
 
         // Exact byte classes of EVERY value of one candidate (0 = snapshot, 1 = log): a second streaming pass over
         // the tile with compact rolled loops, run only when the exact figure matters (see phase 4).  Totals end up
-        // in sh.tot[8..10] (Lmax: > 1, > 2, > 3 bytes) and sh.tot[11..13] (Lmin).
+        // in sh.tot[10..12] (Lmax: > 1, > 2, > 3 bytes) and sh.tot[13..15] (Lmin).
         auto classes_pass = [&](const int which) {
 #ifdef K2R_SIM_TRACE
             if (EX::kSim) __builtin_printf("classes_pass(%d) inst=%u\n", which, inst);
@@ -1187,14 +1215,14 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         }
                     }
                 }
-                r.sc[8] = vMax.c1;
-                r.sc[9] = vMax.c2;
-                r.sc[10] = vMax.c3;
-                r.sc[11] = vMin.c1;
-                r.sc[12] = vMin.c2;
-                r.sc[13] = vMin.c3;
+                r.sc[10] = vMax.c1;
+                r.sc[11] = vMax.c2;
+                r.sc[12] = vMax.c3;
+                r.sc[13] = vMin.c1;
+                r.sc[14] = vMin.c2;
+                r.sc[15] = vMin.c3;
             });
-            ex.template reduce<6, 8>();
+            ex.template reduce<6, 10>();
         };
 
         // ================= phase 4: sizes and the heuristic (chunk.rs:62) ===============================
@@ -1230,7 +1258,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     // everything is computed in this lane's registers and stored once: a chain of LDS round trips
                     // here would be paid by the 1023 threads waiting at the barrier
                     const uint32_t t0 = sh.tot[0], t1 = sh.tot[1], t2 = sh.tot[2], t3 = sh.tot[3], t4 = sh.tot[4], t5 = sh.tot[5],
-                                   t6 = sh.tot[6];
+                                   t6 = sh.tot[6], t7 = sh.tot[7], t8 = sh.tot[8], t9 = sh.tot[9];
                     Totals<C> TS, TL;
                     DacLayout LV{}, LM{};
                     TS.from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);
@@ -1239,9 +1267,17 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         TL.from((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30), t4);
                         narrow = t6 == 0 ? 1u : 0u;
                         eq_off = 13 + bitmap_size(TL.LT);
+                        // second bytes come in level order too: first those of heights >= 3, then height 2, 1, 0
+                        const uint32_t lv2 = t5 & 0xffffu, lv1 = lv2 + (t8 >> 16), lv0 = lv1 + (t8 & 0xffffu);
+                        const uint32_t lm2 = t5 >> 16, lm1 = lm2 + (t9 >> 16);
+                        pl.lngV[0] = lv0;
+                        pl.lngV[1] = lv1;
+                        pl.lngV[2] = lv2;
+                        pl.lngM[1] = lm1;
+                        pl.lngM[2] = lm2;
                         if (narrow) {  // only "> 1 byte" counts are kept inline
-                            LV = dac_layout(eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, t5 & 0x1ffffu, 0, 0);
-                            LM = dac_layout(LV.end, TL.M0, t5 >> 17, 0, 0);
+                            LV = dac_layout(eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, lv0 + t7, 0, 0);
+                            LM = dac_layout(LV.end, TL.M0, lm1 + (t9 & 0xffffu), 0, 0);
                             log_size = LM.end;  // log.rs:95-97
                         } else {
                             need = 1;  // some log value may need 3+ bytes: count exactly first
@@ -1265,19 +1301,19 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         else choose(false, TL, log_size, narrow);
                     }
                     pl.need = need;
-                } else if (stage == 2) {  // exact classes of the log are in sh.tot[8..13]
-                    pl.V[1] = dac_layout(pl.eq_off + bitmap_size(pl.T[1].LT - pl.T[1].M0), pl.T[1].N0, sh.tot[8], sh.tot[9], sh.tot[10]);
-                    pl.M[1] = dac_layout(pl.V[1].end, pl.T[1].M0, sh.tot[11], sh.tot[12], sh.tot[13]);
+                } else if (stage == 2) {  // exact classes of the log are in sh.tot[10..15]
+                    pl.V[1] = dac_layout(pl.eq_off + bitmap_size(pl.T[1].LT - pl.T[1].M0), pl.T[1].N0, sh.tot[10], sh.tot[11], sh.tot[12]);
+                    pl.M[1] = dac_layout(pl.V[1].end, pl.T[1].M0, sh.tot[13], sh.tot[14], sh.tot[15]);
                     pl.log_size = pl.M[1].end;
                     if (cap254 || pl.snap_lb <= pl.log_size) pl.need = 2;
                     else {
                         choose(false, pl.T[1], pl.log_size, pl.narrow);
                         pl.need = 0;
                     }
-                } else {  // exact classes of the snapshot are in sh.tot[8..13]
+                } else {  // exact classes of the snapshot are in sh.tot[10..15]
                     const uint32_t sbase = 13 + bitmap_size(pl.T[0].LT);
-                    pl.V[0] = dac_layout(sbase, pl.T[0].N0, sh.tot[8], sh.tot[9], sh.tot[10]);
-                    pl.M[0] = dac_layout(pl.V[0].end, pl.T[0].M0, sh.tot[11], sh.tot[12], sh.tot[13]);
+                    pl.V[0] = dac_layout(sbase, pl.T[0].N0, sh.tot[10], sh.tot[11], sh.tot[12]);
+                    pl.M[0] = dac_layout(pl.V[0].end, pl.T[0].M0, sh.tot[13], sh.tot[14], sh.tot[15]);
                     const bool snap = !have_s || cap254 || pl.M[0].end <= pl.log_size;
                     choose(snap, pl.T[snap ? 0 : 1], snap ? pl.M[0].end : pl.log_size, pl.narrow);
                     pl.need = 0;
@@ -1330,10 +1366,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         ex.stamp(12);  // sizes + heuristic (wave-uniform arithmetic, lazy class passes)
         // exclusive prefixes of the winner's internal counts (positions)
         ex.par_nosync([&](int, EncRegs& r) {
-            r.sc[0] = as_snapshot ? r.sc[0] : r.sc[3];                      // I1 | I2 << 16
-            r.sc[1] = as_snapshot ? (r.sc[1] & 0xffffu) : (r.sc[1] >> 16);  // I3
+            const uint32_t a = as_snapshot ? r.sc[0] : r.sc[3];                      // I1 | I2 << 16
+            const uint32_t b = as_snapshot ? (r.sc[1] & 0xffffu) : (r.sc[1] >> 16);  // I3
+            const uint32_t c = r.sc[7], d = r.sc[8], e = r.sc[9];                    // second bytes per level (logs)
+            r.sc[0] = a;
+            r.sc[1] = b;
+            r.sc[2] = c;
+            r.sc[3] = d;
+            r.sc[4] = e;
         });
-        ex.template scan<2>();
+        ex.template scan<5>();
         ex.stamp(13);  // scan of the winner's counts
 
         // ================= phase 5: emission of the winner ===============================================
@@ -1347,7 +1389,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV0[w] = 0;
             for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
             r.pf_lo = (uint64_t)r.sc[0] | ((uint64_t)r.sc[1] << 30);  // the lo pack of unpackI
-            sh.pfx[tid] = r.sc[0];
+            r.pf_l2 = (r.sc[3] >> 16) | (r.sc[4] & 0xffff0000u);       // second bytes before this block's height-2 group: Lmax | Lmin << 16
+            sh.pfx[0][tid] = r.sc[0];
+            sh.pfx[1][tid] = r.sc[2];
+            sh.pfx[2][tid] = (r.sc[3] & 0xffffu) | (r.sc[4] << 16);
             if (tid <= C::TBW) {  // rank prefix over the winner's top-node flags (<= 12 words)
                 const uint32_t* const tbw = as_snapshot ? sh.tbS : sh.tbL;
                 uint32_t run = 0;
@@ -1374,7 +1419,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         ex.stamp(4);  // sizes, heuristic, clears, header
         const uint32_t nlevV = ex.uni(DV.nlev), nlevM = ex.uni(DM.nlev);
         const DacSink sinkV{io + ex.uni(DV.by_off[0]), sh.bmV0, listV, &sh.nlistV, ex.uni(DV.n[0]), ex.uni(DV.n[1]), inst, kGuardVPos,
-                            io + ex.uni(DV.by_off[1]), sh.prefV};
+                            io + ex.uni(DV.by_off[1]), use_stash ? sh.prefTopV : sh.prefV()};
         const DacSink sinkM{io + ex.uni(DM.by_off[0]), sh.bmM[0], listM, &sh.nlistM, ex.uni(DM.n[0]), ex.uni(DM.n[1]), inst, kGuardMPos,
                             io + ex.uni(DM.by_off[1]), sh.prefM};
 
@@ -1389,11 +1434,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 
             // -- this thread's own height-3 node and, for the first NTOPX threads, one top node each --
             const uint32_t* const tb = as_snapshot ? sh.tbS : sh.tbL;
-            if (MODE == EM_P0) {
-                r.pa[2] = 0;
-                r.pa[6] = 0;
-                r.pa[8] = 0;
-            }
+            if (MODE == EM_P0) r.pa[2] = 0;
+            // nodes of heights >= 3 are placed by bitmap rank (EM_P0 now, second bytes replayed later); the height-2
+            // group below knows where its second bytes go (EM_ONE)
+            constexpr int GMODE = (MODE == EM_P0) ? (int)EM_ONE : MODE;
             auto enode = [&](int h, uint32_t j, const int slot) {
                 const bool vis = (h == H) ? true : bit_test(tb, tbit(h + 1, j >> 2));
                 if (!vis) return;
@@ -1492,21 +1536,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                     tb2 = (tb2 << 1) | (P2[j] ? 1u : 0u);
                 }
-                emit4<0, MODE>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid);
-                if (MODE == EM_P0) {
-                    r.pa[5] = p2;
-                    r.pa[6] = (z2v[0] >> 8) | ((z2v[1] >> 8) << 8) | ((z2v[2] >> 8) << 16) | ((z2v[3] >> 8) << 24);
-                    r.pa[7] = TT.offI[2] + E2;
-                }
+                emit4<0, GMODE>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid, sh.pl.lngV[2] + (r.pf_l2 & 0xffffu));
                 bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
                 if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
-                uint32_t n2 = 0, pre = E1;
+                uint32_t n2 = 0, pre = E1, lm = sh.pl.lngM[2] + (r.pf_l2 >> 16);
                 const uint32_t cshift = as_snapshot ? 4u : 16u;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (P2[j]) {
-                        emit_val<1, MODE>(ex, sinkM, TT.offI[2] + E2 + n2, zm2[j], tid);
-                        if (MODE == EM_P0) r.pa[8] |= (zm2[j] >> 8) << (8 * n2);
+                        emit_val<1, GMODE>(ex, sinkM, TT.offI[2] + E2 + n2, zm2[j], tid, lm);
+                        lm += zm2[j] > 0xffu ? 1u : 0u;
                         if (MODE == EM_LIST)
                             sh.L2()[guard_pos(ex, E2 + n2, 1, 4 * C::NBLK, kGuardList2)] = ((uint32_t)tid << 2) | (uint32_t)j | (pre << 12);
                         n2++;
@@ -1519,94 +1558,78 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         };
         const uint32_t nI2 = ex.uni(TT.Ni[2]), nI1 = ex.uni(TT.Ni[1]);
         if (use_stash) {
-            // ---- a Log whose values all fit two bytes, emitted from the stash in two passes (EM_P0, EM_P1) ----
-            // one work item per I record: the four height-1 children of an internal height-2 node.  Records are in
-            // arrival order; their place in level order comes from the owner's prefix.
-            auto passI = [&](auto mode_tag) {
-                constexpr int MODE = decltype(mode_tag)::value;
-                ex.par([&](int tid, EncRegs&) {
-                    for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
-                        const uint32_t* rec = sh.pool + 5u * k;
-                        const uint32_t hdr = rec[0];
-                        const uint32_t pf = sh.pfx[hdr & 1023u];
-                        const uint32_t kk = ((pf >> 16) & 0x3fffu) + ((hdr >> 10) & 3u);  // rank among internal height-2 nodes
-                        const uint32_t pre = (pf & 0xffffu) + ((hdr >> 12) & 15u);        // internal quads before this node
-                        const uint32_t tb1 = (hdr >> 16) & 15u, erun = (hdr >> 20) & 15u, elen = (hdr >> 24) & 7u;
-                        uint32_t w[4];
-#pragma unroll
-                        for (int qq = 0; qq < 4; qq++) w[qq] = rec[1 + qq];
-                        const uint32_t p1 = TT.offV[1] + 4 * kk;
-                        emit4<0, MODE>(ex, sinkV, p1, zz32((int32_t)(int16_t)(w[0] & 0xffffu)), zz32((int32_t)(int16_t)(w[1] & 0xffffu)),
-                                       zz32((int32_t)(int16_t)(w[2] & 0xffffu)), zz32((int32_t)(int16_t)(w[3] & 0xffffu)), tid);
-                        if (MODE != EM_P1) {
-                            bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
-                            bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * kk - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
-                        }
-                        uint32_t n1 = 0;
-#pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            if ((tb1 >> (3 - qq)) & 1u) {
-                                emit_val<1, MODE>(ex, sinkM, TT.offI[1] + pre + n1, zz32((int32_t)w[qq] >> 16), tid);
-                                n1++;
-                            }
-                        }
-                    }
-                    guard_flush(ex);
-                });
-            };
-            // one work item per Q record: the four cells of an internal quad
-            auto passQ = [&](auto mode_tag) {
-                constexpr int MODE = decltype(mode_tag)::value;
-                ex.par([&](int tid, EncRegs&) {
-                    for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
-                        const uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
-                        const uint32_t hdr = q[0], a = q[1], b = q[2];
-                        const uint32_t pos = (sh.pfx[hdr & 1023u] & 0xffffu) + ((hdr >> 10) & 15u);  // rank among internal quads
-                        emit4<0, MODE>(ex, sinkV, TT.offV[0] + 4 * pos, zz32((int32_t)(int16_t)(a & 0xffffu)), zz32((int32_t)a >> 16),
-                                       zz32((int32_t)(int16_t)(b & 0xffffu)), zz32((int32_t)b >> 16), tid);
-                    }
-                    guard_flush(ex);
-                });
-            };
-            using P0 = EmTag<EM_P0>;
-            using P1 = EmTag<EM_P1>;
-            passA(P0{});
+            // ---- a Log whose values all fit two bytes, emitted from the stash: every byte of both Dacs is stored in
+            // one visit of each source (EM_ONE), except the second bytes of the few nodes of heights >= 3 ----
+            passA(EmTag<EM_P0>{});
             ex.stamp(10);
-            passI(P0{});
+            // one work item per I record: the four height-1 children of an internal height-2 node.  Records are in
+            // arrival order; their place in level order comes from the owner's prefixes.
+            ex.par([&](int tid, EncRegs&) {
+                const uint32_t offV1 = TT.offV[1], offZ1 = TT.offZ[1], offI1 = TT.offI[1], lt = TT.LT, ne = TT.LT - TT.M0;
+                const uint32_t lv1 = sh.pl.lngV[1], lm1 = sh.pl.lngM[1];
+                for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
+                    const uint32_t* rec = sh.pool + 5u * k;
+                    const uint32_t hdr = rec[0];
+                    const uint32_t own = hdr & 1023u;
+                    const uint32_t pf = sh.pfx[0][own], pl = sh.pfx[2][own];
+                    const uint32_t kk = ((pf >> 16) & 0x3fffu) + ((hdr >> 10) & 3u);  // rank among internal height-2 nodes
+                    const uint32_t pre = (pf & 0xffffu) + ((hdr >> 12) & 15u);        // internal quads before this node
+                    const uint32_t tb1 = (hdr >> 16) & 15u, erun = (hdr >> 20) & 15u, elen = 4u - popc32(tb1);
+                    uint32_t w[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) w[qq] = rec[1 + qq];
+                    const uint32_t p1 = offV1 + 4 * kk;
+                    emit4<0, EM_ONE>(ex, sinkV, p1, zz32((int32_t)(int16_t)(w[0] & 0xffffu)), zz32((int32_t)(int16_t)(w[1] & 0xffffu)),
+                                     zz32((int32_t)(int16_t)(w[2] & 0xffffu)), zz32((int32_t)(int16_t)(w[3] & 0xffffu)), tid,
+                                     lv1 + (pl & 0xffffu) + ((hdr >> 24) & 15u));
+                    bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, lt, kGuardTRun1), 4, tb1);
+                    bm_or_run(ex, sh.bmE, guard_pos(ex, offZ1 + 4 * kk - pre, elen, ne, kGuardE1), elen, erun);
+                    uint32_t n1 = 0, lm = lm1 + (pl >> 16) + (hdr >> 28);
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        if ((tb1 >> (3 - qq)) & 1u) {
+                            const uint32_t zm = zz32((int32_t)w[qq] >> 16);
+                            emit_val<1, EM_ONE>(ex, sinkM, offI1 + pre + n1, zm, tid, lm);
+                            lm += zm > 0xffu ? 1u : 0u;
+                            n1++;
+                        }
+                    }
+                }
+                guard_flush(ex);
+            });
             ex.stamp(11);
-            passQ(P0{});
+            // one work item per Q record: the four cells of an internal quad
+            ex.par([&](int tid, EncRegs&) {
+                const uint32_t offV0 = TT.offV[0], lv0 = sh.pl.lngV[0];
+                for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
+                    const uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
+                    const uint32_t hdr = q[0], a = q[1], b = q[2];
+                    const uint32_t own = hdr & 1023u;
+                    const uint32_t pos = (sh.pfx[0][own] & 0xffffu) + ((hdr >> 10) & 15u);  // rank among internal quads
+                    emit4<0, EM_ONE>(ex, sinkV, offV0 + 4 * pos, zz32((int32_t)(int16_t)(a & 0xffffu)), zz32((int32_t)a >> 16),
+                                     zz32((int32_t)(int16_t)(b & 0xffffu)), zz32((int32_t)b >> 16), tid,
+                                     lv0 + sh.pfx[1][own] + ((hdr >> 14) & 63u));
+                }
+                guard_flush(ex);
+            });
             ex.stamp(6);
-            // T, eqB and the continuation bitmaps of both Dacs (serialized; rank prefixes kept for the second bytes)
+            // T, eqB and the continuation bitmaps of both Dacs (serialized; rank prefixes kept for the top nodes)
             {
                 const uint32_t lt = ex.uni(TT.LT), m0 = ex.uni(TT.M0);
-                const BmJob jobs[4] = {{sh.bmT, lt, nullptr, io + 13},
-                                       {sh.bmE, lt - m0, nullptr, io + log_eq_off},
-                                       {sh.bmV0, sinkV.n0, sh.prefV, nlevV > 0 ? io + ex.uni(DV.bm_off[0]) : nullptr},
-                                       {sh.bmM[0], sinkM.n0, sh.prefM, nlevM > 0 ? io + ex.uni(DM.bm_off[0]) : nullptr}};
+                const BmJob jobs[4] = {{sh.bmT, lt, nullptr, 0, io + 13},
+                                       {sh.bmE, lt - m0, nullptr, 0, io + log_eq_off},
+                                       {sh.bmV0, sinkV.n0, sh.prefTopV, SH::PREFTOP, nlevV > 0 ? io + ex.uni(DV.bm_off[0]) : nullptr},
+                                       {sh.bmM[0], sinkM.n0, sh.prefM, SH::PREFTOP, nlevM > 0 ? io + ex.uni(DM.bm_off[0]) : nullptr}};
                 bitmaps_finish<C, 4>(ex, jobs);
             }
             ex.stamp(8);
             if (nlevV > 1 || nlevM > 1) {
-                // byte 1 of what pass A emitted, replayed from the registers it left behind
-                ex.par([&](int tid, EncRegs& r) {
+                // second bytes of the nodes of heights >= 3, replayed from the registers pass A left behind
+                ex.par_nosync([&](int tid, EncRegs& r) {
                     auto put = [&](const DacSink& d, uint32_t* bm0, uint32_t pos, uint32_t hi) {
                         if (hi) {
-                            pos = guard_pos(ex, pos, 1, d.n0, d.code);
+                            pos = guard_pos(ex, pos, 1, d.n0 < 32u * SH::PREFTOP ? d.n0 : 32u * SH::PREFTOP, d.code);
                             gstore8(d.plane1 + guard_pos(ex, bm_rank(bm0, d.pref, pos), 1, d.n1, d.code + 1), (uint8_t)hi);
-                        }
-                    };
-                    auto put4 = [&](const DacSink& d, uint32_t* bm0, uint32_t pos, uint32_t his) {  // consecutive positions
-                        if (his) {
-                            pos = guard_pos(ex, pos, 4, d.n0 + 3, d.code);
-                            uint32_t q = bm_rank(bm0, d.pref, pos);
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const uint32_t b = (his >> (8 * i)) & 0xffu;
-                                if (b) {
-                                    gstore8(d.plane1 + guard_pos(ex, q, 1, d.n1, d.code + 1), (uint8_t)b);
-                                    q++;
-                                }
-                            }
                         }
                     };
                     const uint32_t hb = r.pa[2];
@@ -1614,17 +1637,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     put(sinkM, sh.bmM[0], r.pa[1], (hb >> 8) & 0xffu);
                     put(sinkV, sh.bmV0, r.pa[3], (hb >> 16) & 0xffu);
                     put(sinkM, sh.bmM[0], r.pa[4], hb >> 24);
-                    put4(sinkV, sh.bmV0, r.pa[5], r.pa[6]);
-                    put4(sinkM, sh.bmM[0], r.pa[7], r.pa[8]);
                     guard_flush(ex);
                 });
                 ex.stamp(14);
-                passI(P1{});
-                ex.stamp(15);
-                passQ(P1{});
-                ex.stamp(16);
                 if (nlevV > 1) bitmap_write_zero<C>(ex, sinkV.n1, io + ex.uni(DV.bm_off[1]));
                 if (nlevM > 1) bitmap_write_zero<C>(ex, sinkM.n1, io + ex.uni(DM.bm_off[1]));
+                // (no barrier: nothing the next instant's first phase writes is read above)
             }
             ex.stamp(9);
         } else {
@@ -1747,7 +1765,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 U.end = ex.uni(L.end);
                 return U;
             };
-            dac_finish<C>(ex, uni_layout(DV), io, sh.bmV0, sh.bmV1(), sh.prefV, listV, &sh.nlistV);
+            dac_finish<C>(ex, uni_layout(DV), io, sh.bmV0, sh.bmV1(), sh.prefV(), listV, &sh.nlistV);
             ex.stamp(8);  // Lmax Dac: bitmaps + planes >= 1
             dac_finish<C>(ex, uni_layout(DM), io, sh.bmM[0], sh.bmM[1], sh.prefM, listM, &sh.nlistM);
             ex.stamp(9);  // Lmin Dac: planes >= 1
