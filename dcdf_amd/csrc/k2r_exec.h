@@ -115,15 +115,17 @@ struct GpuExec {
             if (lane == W - 1) sh.wsum[wave][f] = incl[f];
         }
         lds_barrier();
+        // the NW (<= 16) wave totals of a field sit in lanes 0..NW-1 of every wave: a 4-step row scan turns them into
+        // the wave bases -- one 16-lane LDS read per field instead of NW broadcast reads
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            uint32_t base = 0, tot = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                const uint32_t s = sh.wsum[w][f];
-                base += (w < wave) ? s : 0u;
-                tot += s;
-            }
+            int x = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
+            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(x, NW - 1);
+            const uint32_t base = wave == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane(x, wave - 1);
             r.sc[f] = base + incl[f] - r.sc[f];
             if (tid == 0) sh.tot[f] = tot;
         }
