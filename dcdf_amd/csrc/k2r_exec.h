@@ -82,17 +82,28 @@ struct GpuExec {
         return (uint32_t)x;
     }
 
-    // workgroup sum of r.sc[F0..F0+NF) -> sh.tot[F0..F0+NF) (no prefixes): wave scan + one LDS atomic per wave
+    // workgroup sum of r.sc[F0..F0+NF) -> sh.tot[F0..F0+NF) (no prefixes): wave totals through sh.wsum, then a 16-lane
+    // row reduction of them (no atomics)
     template <int NF, int F0 = 0>
     __device__ __forceinline__ void reduce() {
         constexpr int W = NT < 64 ? NT : 64;
-        for (int f = F0 + tid; f < F0 + NF; f += NT) sh.tot[f] = 0;  // NT may be smaller than NF (sidelen 8, 16)
-        lds_barrier();
+        constexpr int NW = NT < 64 ? 1 : NT / 64;
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int f = F0; f < F0 + NF; f++) {
             const uint32_t inc = wave_incl_scan(r.sc[f]);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, W - 1);
-            if ((tid & 63) == 0) atomicAdd(&sh.tot[f], total);
+            if (lane == W - 1) sh.wsum[wave][f] = inc;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int f = F0; f < F0 + NF; f++) {
+            int x = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
+            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+            if (tid == NW - 1) sh.tot[f] = (uint32_t)x;
         }
         lds_barrier();
     }
