@@ -86,10 +86,13 @@ static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls) {
     const uint32_t S = 1u << lg;
     cls->log2s = (int)lg;
     cls->padded = t.rows != S || t.cols != S;
-    const bool rows16 = !cls->padded && t.stride_c == 1 && (t.stride_r % 4) == 0 && t.stride_r > 0 && (t.stride_t % 4) == 0 &&
+    // 16-byte row loads: unit column stride, rows and instants 16-byte aligned, 32-bit byte offsets inside an instant
+    const uint64_t esz = (t.dtype == DCDF_I64 || t.dtype == DCDF_F64) ? 8 : 4;
+    const int64_t al = (int64_t)(16 / esz);
+    const bool rows16 = !cls->padded && t.stride_c == 1 && (t.stride_r % al) == 0 && t.stride_r > 0 && (t.stride_t % al) == 0 &&
                         ((uintptr_t)t.base % 16) == 0 &&
-                        (uint64_t)(t.rows - 1) * (uint64_t)t.stride_r + t.cols < (1ull << 29);  // 32-bit byte offsets in the kernel
-    cls->vec = !rows16 ? 0 : (t.dtype == DCDF_I32 ? 1 : (t.dtype == DCDF_F32 ? 2 : 0));
+                        ((uint64_t)(t.rows - 1) * (uint64_t)t.stride_r + t.cols) * esz < (1ull << 31);
+    cls->vec = !rows16 ? 0 : (t.dtype == DCDF_I32 ? 1 : (t.dtype == DCDF_F32 ? 2 : (t.dtype == DCDF_I64 ? 3 : 0)));
     return DCDF_OK;
 }
 

@@ -219,12 +219,38 @@ K2R_HD float as_f32(int32_t x) {
 
 // 16 cells of height-2 node j (rows 4*(j>>1).., cols 4*(j&1)..) in local Morton order
 // VEC: 0 = generic (any dtype / strides / padding), 1 = int32 rows loaded 16 bytes at a time, 2 = the same for float32
-// rows, converted to fixed point on the fly.
+// rows, converted to fixed point on the fly, 3 = int64 rows (two 16-byte loads per four cells), narrowed with the range
+// check of the fast path's contract.
 template <bool PADDED, int VEC>
 K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t c0, int j, int32_t (&dst)[16],
                        int32_t& err) {
     const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-    if (VEC) {
+    if (VEC == 3) {
+        const int64_t* ib = (const int64_t*)ta.base + (int64_t)inst * ta.st;
+        const uint32_t o0 = rj * (uint32_t)ta.sr + cj;
+        uint32_t bad = 0;
+#pragma unroll
+        for (int dr = 0; dr < 4; dr++) {
+            const uint32_t o = o0 + (uint32_t)dr * (uint32_t)ta.sr;
+            int64_t x[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef __attribute__((address_space(1))) const char* gptr;
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+            const uint32_t ob = o << 3;  // 32-bit BYTE offset (< 2^31 by the host's test)
+            const ll2 a = *(__attribute__((address_space(1))) const ll2*)((gptr)ib + ob);
+            const ll2 b = *(__attribute__((address_space(1))) const ll2*)((gptr)ib + ob + 16);
+            x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
+#else
+            for (int i = 0; i < 4; i++) x[i] = ib[o + i];
+#endif
+#pragma unroll
+            for (int dc = 0; dc < 4; dc++) {
+                bad |= (uint32_t)(((uint64_t)x[dc] + (uint64_t)VALUE_LIMIT) >> 31 != 0);
+                dst[cell_m(dr, dc)] = (int32_t)x[dc];
+            }
+        }
+        if (bad && err == 0) err = ERR_RANGE;
+    } else if (VEC) {
         // wave-uniform base of the instant (SGPR pair) + a 32-bit element offset per thread: the host only selects
         // this path when (rows-1)*stride_r + cols < 2^31, so the offset arithmetic stays in 32 bits
         const int32_t* ib = (const int32_t*)ta.base + (int64_t)inst * ta.st;
@@ -284,7 +310,28 @@ K2R_HD void sched_fence() {
 // the four cells of the 2x2 quad whose top-left cell is (rq,cq), row-major (== Morton) order
 template <bool PADDED, int VEC>
 K2R_HD void load_quad(const TileArgs& ta, uint32_t inst, uint32_t rq, uint32_t cq, int32_t (&dst)[4], int32_t& err) {
-    if (VEC) {
+    if (VEC == 3) {
+        const int64_t* ib = (const int64_t*)ta.base + (int64_t)inst * ta.st;
+        const uint32_t o0 = rq * (uint32_t)ta.sr + cq;
+        uint32_t bad = 0;
+#pragma unroll
+        for (int dr = 0; dr < 2; dr++) {
+            const uint32_t o = o0 + (uint32_t)dr * (uint32_t)ta.sr;
+            int64_t x0, x1;
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef __attribute__((address_space(1))) const char* gptr;
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+            const ll2 a = *(__attribute__((address_space(1))) const ll2*)((gptr)ib + (o << 3));
+            x0 = a.x; x1 = a.y;
+#else
+            x0 = ib[o]; x1 = ib[o + 1];
+#endif
+            bad |= (uint32_t)(((uint64_t)x0 + (uint64_t)VALUE_LIMIT) >> 31 != 0) | (uint32_t)(((uint64_t)x1 + (uint64_t)VALUE_LIMIT) >> 31 != 0);
+            dst[2 * dr] = (int32_t)x0;
+            dst[2 * dr + 1] = (int32_t)x1;
+        }
+        if (bad && err == 0) err = ERR_RANGE;
+    } else if (VEC) {
         const int32_t* ib = (const int32_t*)ta.base + (int64_t)inst * ta.st;
         const uint32_t o0 = rq * (uint32_t)ta.sr + cq;
 #pragma unroll
@@ -777,8 +824,8 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
 }
 
 // ======================================================================================================
-// The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 (1) or float32 (2)
-// input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
+// The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 (1), float32 (2) or
+// int64 (3) input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
 // ======================================================================================================
 template <class C, bool PADDED, int VEC, class EX>
 K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM) {
