@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE configs[4]: random get_window (fill_window) + search_window queries against the encoded 4096x4096x365
-raster on one GPU (decode-path throughput).  The raster is encoded on the device (same workload as
-`bench.py --workload config2`), the encoded chunks are opened through the C ABI (dcdf_chunk_open), and batches of
-chunk-level queries -- random chunk, random window inside it -- go through dcdf_query_fill_window_batch /
-dcdf_query_search_batch.  A sample of the answers is checked against the synthetic model (brute force)."""
+raster on one GPU (decode-path throughput), as specified in SURVEY.md 8(d) config 5.  The raster is encoded on
+the device (same workload as `bench.py --workload config2`), the encoded chunks are opened through the C ABI
+(dcdf_chunk_open), dataset-level cubes are split into chunk-level sub-queries at tile/segment boundaries and go
+through dcdf_query_fill_window_batch / dcdf_query_search_batch.  A sample of the answers is reassembled and checked
+against the synthetic model (brute force)."""
 import argparse
 import ctypes as C
 import json
@@ -22,8 +23,6 @@ def main():
     ap.add_argument("--queries", type=int, default=1000000)
     ap.add_argument("--batch", type=int, default=250000)
     ap.add_argument("--segments", type=int, default=12, help="time segments of the raster to encode (12 = all 365 instants)")
-    ap.add_argument("--max-t", type=int, default=8)
-    ap.add_argument("--max-side", type=int, default=16)
     args = ap.parse_args()
     import torch
     import dcdf_amd as dc
@@ -51,65 +50,120 @@ def main():
     del flat
     torch.cuda.empty_cache()
 
-    rng = np.random.default_rng(5)
+    # dataset-level cubes (t0 in U[0,365), len_t in U[1,8], h, w in U[1,64], origin uniform,
+    # clipped), half fill_window and half search_window, each split at tile (256) and time-segment (32) boundaries
+    # into chunk-level sub-queries exactly where Superchunk::subchunks_for / Span::fill_window would split them.
+    rng = np.random.default_rng(0xDCDF0005)
+    smp = synth.cells(0xDCDF0003, 0, 365, 1000, 1064, 2000, 2064, np.int32).ravel()
+    edges = np.percentile(smp, np.arange(0, 101, 10)).astype(np.int64)
+    PCT = np.stack([edges[:-1], edges[1:]], axis=1)  # ten 10-percentile-wide bands of the value range
     nq = args.queries
+    TT = min(365, 32 * args.segments)
     res = {"chunks": len(chunks), "open_seconds": open_s, "queries": nq}
     fw_ms = fw_wall = se_ms = se_wall = 0.0
-    cells = hits = 0
+    cells = hits = nsub_f = nsub_s = 0
     checked = 0
+    chunk_T = np.array([c.shape()[0] for c in chunks])
+
+    def make(n):
+        t0 = rng.integers(0, TT, n)
+        t1 = np.minimum(TT, t0 + rng.integers(1, 9, n))
+        r0 = rng.integers(0, 4096, n)
+        r1 = np.minimum(4096, r0 + rng.integers(1, 65, n))
+        c0 = rng.integers(0, 4096, n)
+        c1 = np.minimum(4096, c0 + rng.integers(1, 65, n))
+        subs = []  # (query id, chunk id, local cube)
+        qid = np.arange(n)
+        for dt in (0, 1):
+            for dr in (0, 1):
+                for dc in (0, 1):
+                    seg, ti, tj = t0 // 32 + dt, r0 // 256 + dr, c0 // 256 + dc
+                    a0, a1 = np.maximum(t0, seg * 32), np.minimum(t1, seg * 32 + 32)
+                    b0, b1 = np.maximum(r0, ti * 256), np.minimum(r1, ti * 256 + 256)
+                    d0, d1 = np.maximum(c0, tj * 256), np.minimum(c1, tj * 256 + 256)
+                    ok = (a1 > a0) & (b1 > b0) & (d1 > d0)
+                    cid = (seg * 256 + ti * 16 + tj)[ok]
+                    subs.append(np.stack([qid[ok], cid, (a0 - seg * 32)[ok], (a1 - seg * 32)[ok], (b0 - ti * 256)[ok],
+                                          (b1 - ti * 256)[ok], (d0 - tj * 256)[ok], (d1 - tj * 256)[ok]], axis=1))
+        sub = np.concatenate(subs)
+        sub = sub[np.argsort(sub[:, 0], kind="stable")]
+        return (t0, t1, r0, r1, c0, c1), sub
+
+    def brute(q, spec):
+        t0, t1, r0, r1, c0, c1 = (int(x[q]) for x in spec)
+        return synth.cells(0xDCDF0003, t0, t1, r0, r1, c0, c1, np.int32), (t0, r0, c0)
+
     for b0 in range(0, nq, args.batch):
         n = min(args.batch, nq - b0)
-        ci = rng.integers(0, len(chunks), n)
-        T = np.array([chunks[c].shape()[0] for c in ci])
-        s = (rng.random(n) * T).astype(np.int64)
-        e = np.minimum(T, s + rng.integers(1, args.max_t + 1, n))
-        t = rng.integers(0, S, n)
-        bo = np.minimum(S, t + rng.integers(1, args.max_side + 1, n))
-        l = rng.integers(0, S, n)
-        r = np.minimum(S, l + rng.integers(1, args.max_side + 1, n))
-        cub = np.stack([s, e, t, bo, l, r], axis=1).astype(np.uint32)
-        cubes = cub.ctypes.data_as(C.POINTER(L.Cube))
-        vol = ((e - s) * (bo - t) * (r - l)).astype(np.uint64)
+        half = n // 2
+        # ---- fill_window half
+        spec, sub = make(half)
+        m = len(sub)
+        cub = np.ascontiguousarray(sub[:, 2:8].astype(np.uint32))
+        vol = ((sub[:, 3] - sub[:, 2]) * (sub[:, 5] - sub[:, 4]) * (sub[:, 7] - sub[:, 6])).astype(np.uint64)
         woff = np.concatenate([[0], np.cumsum(vol)[:-1]]).astype(np.uint64)
         total = int(vol.sum())
-        handles = (C.c_void_p * n)(*[chunks[c]._h for c in ci])
+        handles = (C.c_void_p * m)(*[chunks[c]._h for c in sub[:, 1]])
         out = np.empty(total, dtype=np.int64)
         ms = C.c_float()
         w0 = time.perf_counter()
-        L.check(L.lib().dcdf_query_fill_window_batch(handles, cubes, C.c_size_t(n), C.c_void_p(out.ctypes.data),
-                                                     C.c_void_p(woff.ctypes.data), C.byref(ms)), "fill_window_batch")
+        L.check(L.lib().dcdf_query_fill_window_batch(handles, cub.ctypes.data_as(C.POINTER(L.Cube)), C.c_size_t(m),
+                                                     C.c_void_p(out.ctypes.data), C.c_void_p(woff.ctypes.data), C.byref(ms)),
+                "fill_window_batch")
         fw_wall += time.perf_counter() - w0
         fw_ms += ms.value
         cells += total
-        # value band of about a tenth of the raster's range around a random level
-        lower = rng.integers(-300, 300, n).astype(np.int64)
-        upper = lower + 60
-        counts = np.zeros(n, dtype=np.uint64)
-        soff = np.zeros(n, dtype=np.uint64)
+        nsub_f += m
+        for q in rng.integers(0, half, 20):  # spot check: reassemble the dataset-level window from its pieces
+            ref, (t0, r0, c0) = brute(q, spec)
+            got = np.zeros_like(ref, dtype=np.int64)
+            for k in np.nonzero(sub[:, 0] == q)[0]:
+                _, cid, a0, a1, b0_, b1, d0, d1 = (int(x) for x in sub[k])
+                seg, ti, tj = cid // 256, (cid // 16) % 16, cid % 16
+                piece = out[int(woff[k]):int(woff[k]) + int(vol[k])].reshape(a1 - a0, b1 - b0_, d1 - d0)
+                got[seg * 32 + a0 - t0:seg * 32 + a1 - t0, ti * 256 + b0_ - r0:ti * 256 + b1 - r0,
+                    tj * 256 + d0 - c0:tj * 256 + d1 - c0] = piece
+            assert (got == ref).all(), "fill_window mismatch"
+            checked += 1
+        # ---- search_window half: [lower, upper] = a random 10-percentile-wide band of the value range
+        spec, sub = make(n - half)
+        m = len(sub)
+        cub = np.ascontiguousarray(sub[:, 2:8].astype(np.uint32))
+        vol = ((sub[:, 3] - sub[:, 2]) * (sub[:, 5] - sub[:, 4]) * (sub[:, 7] - sub[:, 6])).astype(np.uint64)
+        total = int(vol.sum())
+        handles = (C.c_void_p * m)(*[chunks[c]._h for c in sub[:, 1]])
+        qlo = PCT[rng.integers(0, 10, n - half)]
+        lower = np.ascontiguousarray(qlo[:, 0][sub[:, 0]]).astype(np.int64)
+        upper = np.ascontiguousarray(qlo[:, 1][sub[:, 0]]).astype(np.int64)
+        counts = np.zeros(m, dtype=np.uint64)
+        soff = np.zeros(m, dtype=np.uint64)
         trip = np.empty((total, 3), dtype=np.uint32)
         w0 = time.perf_counter()
-        L.check(L.lib().dcdf_query_search_batch(handles, cubes, C.c_void_p(lower.ctypes.data), C.c_void_p(upper.ctypes.data),
-                                                C.c_size_t(n), C.c_void_p(trip.ctypes.data), C.c_size_t(total),
-                                                C.c_void_p(counts.ctypes.data), C.c_void_p(soff.ctypes.data), C.byref(ms)),
-                "search_batch")
+        L.check(L.lib().dcdf_query_search_batch(handles, cub.ctypes.data_as(C.POINTER(L.Cube)), C.c_void_p(lower.ctypes.data),
+                                                C.c_void_p(upper.ctypes.data), C.c_size_t(m), C.c_void_p(trip.ctypes.data),
+                                                C.c_size_t(total), C.c_void_p(counts.ctypes.data), C.c_void_p(soff.ctypes.data),
+                                                C.byref(ms)), "search_batch")
         se_wall += time.perf_counter() - w0
         se_ms += ms.value
         hits += int(counts.sum())
-        for q in rng.integers(0, n, 25):  # spot check against the synthetic model
-            seg, i, j = grid[ci[q]]
-            ref = synth.cells(0xDCDF0003, 32 * seg + int(s[q]), 32 * seg + int(e[q]), S * i + int(t[q]), S * i + int(bo[q]),
-                              S * j + int(l[q]), S * j + int(r[q]), np.int32)
-            got = out[int(woff[q]):int(woff[q]) + int(vol[q])].reshape(ref.shape)
-            assert (got == ref).all(), "fill_window mismatch"
-            tr = trip[int(soff[q]):int(soff[q]) + int(counts[q])]
-            m = (ref >= lower[q]) & (ref <= upper[q])
-            exp = np.argwhere(m) + np.array([int(s[q]), int(t[q]), int(l[q])])
-            assert sorted(map(tuple, tr.tolist())) == sorted(map(tuple, exp.tolist())), "search mismatch"
+        nsub_s += m
+        for q in rng.integers(0, n - half, 20):
+            ref, (t0, r0, c0) = brute(q, spec)
+            want = set(map(tuple, (np.argwhere((ref >= qlo[q, 0]) & (ref <= qlo[q, 1])) + np.array([t0, r0, c0])).tolist()))
+            got = set()
+            for k in np.nonzero(sub[:, 0] == q)[0]:
+                cid = int(sub[k, 1])
+                seg, ti, tj = cid // 256, (cid // 16) % 16, cid % 16
+                tr = trip[int(soff[k]):int(soff[k]) + int(counts[k])].astype(np.int64)
+                got |= set(map(tuple, (tr + np.array([seg * 32, ti * 256, tj * 256])).tolist()))
+            assert got == want, "search mismatch"
             checked += 1
-    res.update({"fill_window": {"queries_per_s_kernel": nq / (fw_ms * 1e-3), "cells_per_s_kernel": cells / (fw_ms * 1e-3),
-                                "queries_per_s_end_to_end": nq / fw_wall, "kernel_ms": fw_ms, "cells": cells},
-                "search_window": {"queries_per_s_kernel": nq / (se_ms * 1e-3), "queries_per_s_end_to_end": nq / se_wall,
-                                  "kernel_ms": se_ms, "hits": hits},
+    nqf, nqs = nq // 2, nq - nq // 2
+    res.update({"fill_window": {"queries": nqf, "chunk_level_subqueries": nsub_f, "queries_per_s_kernel": nqf / (fw_ms * 1e-3),
+                                "cells_per_s_kernel": cells / (fw_ms * 1e-3), "queries_per_s_end_to_end": nqf / fw_wall,
+                                "kernel_ms": fw_ms, "cells": cells},
+                "search_window": {"queries": nqs, "chunk_level_subqueries": nsub_s, "queries_per_s_kernel": nqs / (se_ms * 1e-3),
+                                  "queries_per_s_end_to_end": nqs / se_wall, "kernel_ms": se_ms, "hits": hits},
                 "answers_checked_vs_model": checked})
     print(json.dumps(res))
 
