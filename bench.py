@@ -159,6 +159,16 @@ def main():
             cpu = {"value": sample.size / sec, "unit": "cells/s", "cores": 1, "kind": "port",
                    "sample": "first %d of the %d [%d,%d,%d] %s chunks (%.1f s); C++ restatement of the Rust "
                              "reference, serial like superchunk.rs:166-188" % (m, n, T, S, S, args.dtype, sec)}
+            # the same port with one chunk per task on every host core (the reference itself is serial)
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(16, len(os.sched_getaffinity(0))))  # a one-GPU box's CPU share is 16 cores
+            reps = [sample[i % m:i % m + 1] for i in range(2 * nthr)]
+            w0 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(O.bench_build, reps))  # ctypes releases the GIL inside the call
+            wall = time.perf_counter() - w0
+            cpu["all_cores"] = {"value": sum(r.size for r in reps) / wall, "unit": "cells/s", "cores": nthr,
+                                "sample": "%d chunk builds on %d threads (%.1f s)" % (len(reps), nthr, wall)}
 
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
