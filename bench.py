@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=1024, help="chunks per GPU (configs[1]: 1024)")
     ap.add_argument("--instants", type=int, default=32)
     ap.add_argument("--side", type=int, default=256)
-    ap.add_argument("--dtype", choices=["i32", "i64", "f32"], default="i32",
+    ap.add_argument("--dtype", choices=["i32", "i64", "f32", "f64"], default="i32",
                     help="i32 (default): stored fixed-point integers; f32: floats converted on the fly (to_fixed, --fbits)")
     ap.add_argument("--fbits", type=int, default=3, help="fractional bits of the f32 workload")
     ap.add_argument("--cpu-sample", type=int, default=24, help="chunks timed on the CPU oracle (0 = skip)")
@@ -70,9 +70,9 @@ def main():
         raise RuntimeError("libdcdf_k2r.so sees no GPU; the MI355X path has no CPU fallback")
 
     n, T, S = args.chunks, args.instants, args.side
-    tdt = {"i32": torch.int32, "i64": torch.int64, "f32": torch.int32}[args.dtype]
-    code = {"i32": L.DCDF_I32, "i64": L.DCDF_I64, "f32": L.DCDF_I32}[args.dtype]
-    esz = 8 if args.dtype == "i64" else 4
+    tdt = {"i32": torch.int32, "i64": torch.int64, "f32": torch.int32, "f64": torch.int32}[args.dtype]
+    code = {"i32": L.DCDF_I32, "i64": L.DCDF_I64, "f32": L.DCDF_I32, "f64": L.DCDF_I32}[args.dtype]
+    esz = 8 if args.dtype in ("i64", "f64") else 4
     fb = 0
     if args.workload == "config1":
         per = T * S * S + args.pad_elems
@@ -104,13 +104,13 @@ def main():
             data.append(v)
         workload = "configs[2]: 4096x4096x365 %s raster, seed 0xDCDF0003, %d of 3072 [<=32,256,256] chunks on this GPU" % (args.dtype, n)
     torch.cuda.synchronize()
-    if args.dtype == "f32":  # the same integers as exact multiples of 2^-fbits in float32 (|v| < 2^24)
+    if args.dtype in ("f32", "f64"):  # the same integers as exact multiples of 2^-fbits in floating point (|v| < 2^24)
         fb = args.fbits
         assert int(flat.abs().max().item()) < (1 << 24)
-        flat2 = flat.to(torch.float32) / float(1 << fb)
+        flat2 = flat.to(torch.float32 if args.dtype == "f32" else torch.float64) / float(1 << fb)
         data = [flat2[d.storage_offset():d.storage_offset() + d.numel()].view(d.shape) for d in data]
         flat = flat2
-        code = L.DCDF_F32
+        code = L.DCDF_F32 if args.dtype == "f32" else L.DCDF_F64
 
     descs = [(d.data_ptr(), code, (S * S, S, 1), tuple(d.shape), fb, 0) for d in data]
     enc = Encoder(descs, k=2)
@@ -193,14 +193,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"i32": "int32", "i64": "int64", "f32": "f32->fixed(int32 arithmetic)"}[args.dtype],
+            "dtype": {"i32": "int32", "i64": "int64", "f32": "f32->fixed(int32 arithmetic)", "f64": "f64->fixed(int32 arithmetic)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": workload,
                        "chunks_per_gpu": n, "k": 2, "device": name.decode(), "failed_tiles": bad,
                        "encoded_bytes_per_gpu": out_bytes, "snapshots": snaps, "bytes_verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k2r::k_encode<%d,false,%d>" % (S.bit_length() - 1, 2 if args.dtype == "f32" else (1 if args.dtype == "i32" else 0)),
+                         "kernel": "k2r::k_encode<%d,false,%d>" % (S.bit_length() - 1, {"i32": 1, "f32": 2, "i64": 3, "f64": 4}[args.dtype]),
                          "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes},
             "cpu_baseline": cpu,
         }

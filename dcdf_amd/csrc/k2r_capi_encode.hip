@@ -92,7 +92,7 @@ static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls) {
     const bool rows16 = !cls->padded && t.stride_c == 1 && (t.stride_r % al) == 0 && t.stride_r > 0 && (t.stride_t % al) == 0 &&
                         ((uintptr_t)t.base % 16) == 0 &&
                         ((uint64_t)(t.rows - 1) * (uint64_t)t.stride_r + t.cols) * esz < (1ull << 31);
-    cls->vec = !rows16 ? 0 : (t.dtype == DCDF_I32 ? 1 : (t.dtype == DCDF_F32 ? 2 : (t.dtype == DCDF_I64 ? 3 : 0)));
+    cls->vec = !rows16 ? 0 : (t.dtype == DCDF_I32 ? 1 : (t.dtype == DCDF_F32 ? 2 : (t.dtype == DCDF_I64 ? 3 : 4)));
     return DCDF_OK;
 }
 

@@ -211,6 +211,27 @@ K2R_HD void fixed4_f32(const float (&f)[4], const TileArgs& ta, float scale, int
         for (int i = 0; i < 4; i++) v[i] = narrow(to_fixed_dev<float>(f[i], ta.fbits, ta.round != 0, err), err);
     }
 }
+// the same for float64 cells (VEC == 4)
+K2R_HD void fixed4_f64(const double (&f)[4], const TileArgs& ta, double scale, int32_t (&v)[4], int32_t& err) {
+    bool all = ta.round == 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double w = f[i] * scale;
+        const bool isn = f[i] != f[i];
+        const bool ok = isn || (w == __builtin_trunc(w) && __builtin_fabs(w) < 536870912.0);
+        all = all && ok;
+        v[i] = (ok && !isn) ? (int32_t)w * 2 + 1 : 0;
+    }
+    if (!all) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = narrow(to_fixed_dev<double>(f[i], ta.fbits, ta.round != 0, err), err);
+    }
+}
+K2R_HD double as_f64(int64_t x) {
+    double f;
+    __builtin_memcpy(&f, &x, 8);
+    return f;
+}
 K2R_HD float as_f32(int32_t x) {
     float f;
     __builtin_memcpy(&f, &x, 4);
@@ -220,12 +241,12 @@ K2R_HD float as_f32(int32_t x) {
 // 16 cells of height-2 node j (rows 4*(j>>1).., cols 4*(j&1)..) in local Morton order
 // VEC: 0 = generic (any dtype / strides / padding), 1 = int32 rows loaded 16 bytes at a time, 2 = the same for float32
 // rows, converted to fixed point on the fly, 3 = int64 rows (two 16-byte loads per four cells), narrowed with the range
-// check of the fast path's contract.
+// check of the fast path's contract, 4 = float64 rows, converted like float32 ones.
 template <bool PADDED, int VEC>
 K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t c0, int j, int32_t (&dst)[16],
                        int32_t& err) {
     const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
-    if (VEC == 3) {
+    if (VEC == 3 || VEC == 4) {
         const int64_t* ib = (const int64_t*)ta.base + (int64_t)inst * ta.st;
         const uint32_t o0 = rj * (uint32_t)ta.sr + cj;
         uint32_t bad = 0;
@@ -243,10 +264,18 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
 #else
             for (int i = 0; i < 4; i++) x[i] = ib[o + i];
 #endif
+            if (VEC == 4) {
+                const double f[4] = {as_f64(x[0]), as_f64(x[1]), as_f64(x[2]), as_f64(x[3])};
+                int32_t v[4];
+                fixed4_f64(f, ta, (double)((int64_t)1 << ta.fbits), v, err);
 #pragma unroll
-            for (int dc = 0; dc < 4; dc++) {
-                bad |= (uint32_t)(((uint64_t)x[dc] + (uint64_t)VALUE_LIMIT) >> 31 != 0);
-                dst[cell_m(dr, dc)] = (int32_t)x[dc];
+                for (int dc = 0; dc < 4; dc++) dst[cell_m(dr, dc)] = v[dc];
+            } else {
+#pragma unroll
+                for (int dc = 0; dc < 4; dc++) {
+                    bad |= (uint32_t)(((uint64_t)x[dc] + (uint64_t)VALUE_LIMIT) >> 31 != 0);
+                    dst[cell_m(dr, dc)] = (int32_t)x[dc];
+                }
             }
         }
         if (bad && err == 0) err = ERR_RANGE;
@@ -310,10 +339,11 @@ K2R_HD void sched_fence() {
 // the four cells of the 2x2 quad whose top-left cell is (rq,cq), row-major (== Morton) order
 template <bool PADDED, int VEC>
 K2R_HD void load_quad(const TileArgs& ta, uint32_t inst, uint32_t rq, uint32_t cq, int32_t (&dst)[4], int32_t& err) {
-    if (VEC == 3) {
+    if (VEC == 3 || VEC == 4) {
         const int64_t* ib = (const int64_t*)ta.base + (int64_t)inst * ta.st;
         const uint32_t o0 = rq * (uint32_t)ta.sr + cq;
         uint32_t bad = 0;
+        int64_t raw[4];
 #pragma unroll
         for (int dr = 0; dr < 2; dr++) {
             const uint32_t o = o0 + (uint32_t)dr * (uint32_t)ta.sr;
@@ -326,9 +356,18 @@ K2R_HD void load_quad(const TileArgs& ta, uint32_t inst, uint32_t rq, uint32_t c
 #else
             x0 = ib[o]; x1 = ib[o + 1];
 #endif
-            bad |= (uint32_t)(((uint64_t)x0 + (uint64_t)VALUE_LIMIT) >> 31 != 0) | (uint32_t)(((uint64_t)x1 + (uint64_t)VALUE_LIMIT) >> 31 != 0);
-            dst[2 * dr] = (int32_t)x0;
-            dst[2 * dr + 1] = (int32_t)x1;
+            raw[2 * dr] = x0;
+            raw[2 * dr + 1] = x1;
+        }
+        if (VEC == 4) {
+            const double f[4] = {as_f64(raw[0]), as_f64(raw[1]), as_f64(raw[2]), as_f64(raw[3])};
+            fixed4_f64(f, ta, (double)((int64_t)1 << ta.fbits), dst, err);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bad |= (uint32_t)(((uint64_t)raw[i] + (uint64_t)VALUE_LIMIT) >> 31 != 0);
+                dst[i] = (int32_t)raw[i];
+            }
         }
         if (bad && err == 0) err = ERR_RANGE;
     } else if (VEC) {
@@ -825,7 +864,7 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
 
 // ======================================================================================================
 // The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 (1), float32 (2) or
-// int64 (3) input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
+// int64 (3) / float64 (4) input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
 // ======================================================================================================
 template <class C, bool PADDED, int VEC, class EX>
 K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM) {

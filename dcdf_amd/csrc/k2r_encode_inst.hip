@@ -1,5 +1,5 @@
 // k2r_encode_inst.hip -- ONE instantiation of the fused encoder kernel per translation unit
-// (compiled with -DK2R_L=<log2 sidelen> -DK2R_P=<0|1 padded> -DK2R_V=<0|1|2|3 vector loads: none, int32, float32, int64>): the 30
+// (compiled with -DK2R_L=<log2 sidelen> -DK2R_P=<0|1 padded> -DK2R_V=<0..4 row loader: generic, int32, float32, int64, float64>): the 36
 // instantiations are large, fully unrolled kernels and build in parallel this way.
 #include <hip/hip_runtime.h>
 

@@ -28,6 +28,7 @@ static void run_l(const TileArgs& ta, TileResult* res, bool padded, int vec) {
     else if (vec == 1) run<LOG2S, false, 1>(ta, res);
     else if (vec == 2) run<LOG2S, false, 2>(ta, res);
     else if (vec == 3) run<LOG2S, false, 3>(ta, res);
+    else if (vec == 4) run<LOG2S, false, 4>(ta, res);
     else run<LOG2S, false, 0>(ta, res);
 }
 
@@ -54,7 +55,7 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
     const int64_t al = (int64_t)(16 / esz);
     const bool rows16 = !force_novec && !padded && sc == 1 && (sr % al) == 0 && sr > 0 && (st % al) == 0 && ((uintptr_t)base % 16) == 0 &&
                         ((uint64_t)(rows - 1) * (uint64_t)sr + cols) * esz < (1ull << 31);
-    const int vec = !rows16 ? 0 : (dtype == ENC_I32 ? 1 : (dtype == ENC_F32 ? 2 : (dtype == ENC_I64 ? 3 : 0)));
+    const int vec = !rows16 ? 0 : (dtype == ENC_I32 ? 1 : (dtype == ENC_F32 ? 2 : (dtype == ENC_I64 ? 3 : 4)));
     TileResult res{};
     switch (lg) {
         case 3: run_l<3>(ta, &res, padded, vec); break;

@@ -200,29 +200,30 @@ def test_value_range_contract_int32_rows():
     check(a)
 
 
+@pytest.mark.parametrize("ftype", [np.float32, np.float64])
 @pytest.mark.parametrize("side", [16, 64])
-def test_float32_rows_fast_conversion(side):
+def test_float32_rows_fast_conversion(side, ftype):
     """float32 tiles with aligned rows take the converting row loader (fixed4_f32); everything its fast path does not
     cover (NaN, fractions beyond the chosen bits with rounding, negative fractions, huge values) must agree with
     to_fixed (fixed.rs:31-71) as restated by the oracle."""
     rng = np.random.default_rng(side)
     base = rng.integers(-2000, 2000, size=(side, side))
     a = np.stack([base + rng.integers(-30, 30, size=(side, side)) * (rng.random((side, side)) < 0.2) for _ in range(6)])
-    f = (a / 8.0).astype(np.float32)
+    f = (a / 8.0).astype(ftype)
     f[2, 3, 5] = np.nan
     f[4, 0, 0] = np.nan
     check(f, fractional_bits=3)
     check(f, fractional_bits=5)
     g = f.copy()
-    g[1, 7, 7] = np.float32(5.0 + 1 / 64.0)  # a positive value that needs 6 bits
+    g[1, 7, 7] = ftype(5.0 + 1 / 64.0)  # a positive value that needs 6 bits
     assert S.encode(g, fractional_bits=3)[0] == -3  # precision loss without rounding (fixed.rs:47-59)
     check(g, fractional_bits=3, round_=True)
-    g[1, 7, 7] = np.float32(-1.3)  # negative fraction: the reference neither rounds nor rejects it (fixed.rs:45)
+    g[1, 7, 7] = ftype(-1.3)  # negative fraction: the reference neither rounds nor rejects it (fixed.rs:45)
     check(g, fractional_bits=3)
     h = f.copy()
-    h[3, 2, 2] = np.float32(3e8)  # stored value beyond the fast path's 2^30 contract
+    h[3, 2, 2] = ftype(3e8)  # stored value beyond the fast path's 2^30 contract
     assert S.encode(h, fractional_bits=3)[0] == -8
-    h[3, 2, 2] = np.float32(1e30)  # beyond i64: the reference panics (fixed.rs:62-68)
+    h[3, 2, 2] = ftype(1e30)  # beyond i64: the reference panics (fixed.rs:62-68)
     assert S.encode(h, fractional_bits=3)[0] == -4
     h[3, 2, 2] = -np.inf
     assert S.encode(h, fractional_bits=3)[0] == -2
