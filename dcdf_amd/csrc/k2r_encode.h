@@ -317,6 +317,40 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
     }
 }
 
+// The compact copy of a block's snapshot instant (see encode_chunk): 16 cells of sub-block j of thread tid, uint16
+// offsets from `base`, at words [(j * NT + tid) * 8, +8).
+template <class C>
+K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int32_t (&dst)[16]) {
+    const uint32_t* p = scmp + ((size_t)j * C::NT + (size_t)tid) * 8;
+    uint32_t w[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 a = *(__attribute__((address_space(1))) const uint4*)p;
+    const uint4 b = *(__attribute__((address_space(1))) const uint4*)(p + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+#else
+    for (int i = 0; i < 8; i++) w[i] = p[i];
+#endif
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        dst[2 * i] = base + (int32_t)(w[i] & 0xffffu);
+        dst[2 * i + 1] = base + (int32_t)(w[i] >> 16);
+    }
+}
+template <class C>
+K2R_HD void store_compact(uint32_t* scmp, int tid, int j, int32_t base, const int32_t (&src)[16]) {
+    uint32_t* p = scmp + ((size_t)j * C::NT + (size_t)tid) * 8;
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = (uint32_t)(src[2 * i] - base) | ((uint32_t)(src[2 * i + 1] - base) << 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+    *(__attribute__((address_space(1))) uint4*)p = uint4{w[0], w[1], w[2], w[3]};
+    *(__attribute__((address_space(1))) uint4*)(p + 4) = uint4{w[4], w[5], w[6], w[7]};
+#else
+    for (int i = 0; i < 8; i++) p[i] = w[i];
+#endif
+}
+
 // Returns v, but opaque to the optimizer.  Everything derived from the thread index alone (block origin, the top
 // node a thread looks after, bit positions...) is invariant across instants AND chunks; LICM hoists it to the
 // kernel prologue, where under the 128-VGPR cap it is spilled, to be reloaded from scratch in every instant -- behind
@@ -867,7 +901,7 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
 // int64 (3) / float64 (4) input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
 // ======================================================================================================
 template <class C, bool PADDED, int VEC, class EX>
-K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM) {
+K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM, uint32_t* scmp) {
     constexpr int H = C::H;
     constexpr int NT = C::NT;
     auto& sh = ex.sh;
@@ -906,6 +940,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     uint32_t blk_hdr = 6;        // where the open block's n_instants byte goes (block.rs:89)
     uint32_t blk_count = 0;      // instants in the open block
     uint32_t s_idx = 0;          // instant of the open block's snapshot (chunk.rs:52)
+    // The open block's snapshot instant is compared with every later instant of the block, so it is read 30 times as
+    // often as anything else.  When the instant's range fits 16 bits, a compact copy (cell - minimum as uint16, laid out
+    // [sub-block][thread][16 cells] so that a wave reads 2 KB contiguous) is kept in global scratch and read instead:
+    // 2 bytes per cell whatever the input type, already converted to fixed point.
+    bool s_cmp = false;
+    int32_t s_base = 0;
     uint32_t n_snap = 0, n_log = 0, n_stash = 0;
     int32_t status = ST_OK;
 
@@ -977,7 +1017,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 // ---- log candidate vs. the open block's snapshot (log.rs:112-165, 725-817) ----
                 if (have_s) {
                     int32_t s16[16];
-                    load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
+                    if (s_cmp) load_compact<C>(scmp, tid, j, s_base, s16);
+                    else load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
                     int32_t smn1[4], smx1[4], df1[4];
                     bool eq1[4];
                     uint32_t recw[4], tb1 = 0, erun = 0;  // the I record of this node (see EncShared::pool)
@@ -1440,6 +1481,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             blk_count = 0;
             s_idx = inst;
             n_snap++;
+            const int32_t rmin = ex.uni(sh.tmin[C::top_off(H)]), rmax = ex.uni(sh.tmax[C::top_off(H)]);
+            s_base = rmin;
+            s_cmp = (int64_t)rmax - (int64_t)rmin <= 65535 && inst + 1 < ta.instants;
         } else {
             n_log++;
         }
@@ -1732,6 +1776,20 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
             ex.stamp(9);
         } else {
+            if (as_snapshot && s_cmp) {  // leave the compact copy of this snapshot instant for the logs that follow
+                ex.par_nosync([&](int tid, EncRegs&) {
+                    uint32_t r0, c0;
+                    blk_origin(tid, r0, c0);
+                    int32_t lerr = 0;
+#pragma unroll 1
+                    for (int j = 0; j < 4; j++) {
+                        int32_t t16[16];
+                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
+                        store_compact<C>(scmp, tid, j, s_base, t16);
+                    }
+                });
+                ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
+            }
             passA(EmTag<EM_LIST>{});
             ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
             // 5b'. one work item per internal height-2 node (dense, level order): its four height-1 children

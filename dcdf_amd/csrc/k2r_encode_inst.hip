@@ -19,8 +19,10 @@ k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, c
     using C = EncCfg<LOG2S>;
     __shared__ EncShared<C> sh;
     GpuExec<EncShared<C>, EncRegs, C::NT> ex(sh);
-    uint64_t* listV = lists + (size_t)blockIdx.x * (C::MAXV + C::MAXT + 2);
+    // per-workgroup global scratch: the two overflow lists and the compact snapshot copy (16 u64 words per thread)
+    uint64_t* listV = lists + (size_t)blockIdx.x * (C::MAXV + C::MAXT + 2 + 16 * C::NT);
     uint64_t* listM = listV + (C::MAXV + 1);
+    uint32_t* scmp = (uint32_t*)(listM + (C::MAXT + 1));
     for (;;) {
         if (threadIdx.x == 0) sh.work = atomicAdd(queue, 1u);
         __syncthreads();
@@ -30,7 +32,7 @@ k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, c
         __syncthreads();
         if (w >= n) break;  // uniform: every wave of the workgroup leaves together
         const uint32_t ti = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[w]);
-        encode_chunk<C, PADDED, VEC>(ex, tiles[ti], &results[ti], listV, listM);
+        encode_chunk<C, PADDED, VEC>(ex, tiles[ti], &results[ti], listV, listM, scmp);
     }
 }
 
