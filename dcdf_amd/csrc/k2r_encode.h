@@ -1247,7 +1247,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[6] = wide;
         });
         ex.stamp(2);  // phase 3: own/top nodes
-        ex.template reduce<10>();
+        ex.template reduce_begin<10>();  // the sums are combined by the planning thread itself (phase 4)
         ex.stamp(3);  // totals of the 4 packed fields
 
         // Exact byte classes of EVERY value of one candidate (0 = snapshot, 1 = log): a second streaming pass over
@@ -1359,7 +1359,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         const bool cap254 = have_s && (blk_count - 1 == 254);  // chunk.rs:62 (checked first)
         auto plan = [&](const int stage) {
             ex.par([&](int tid, EncRegs&) {
-                if (tid != 0) return;
+                uint32_t T10[10];
+                if (stage == 1) ex.template totals<10>(T10);  // every thread takes part; the sums land in thread planner()
+                if (tid != (stage == 1 ? EX::planner() : 0)) return;
                 auto& pl = sh.pl;
                 // the decision: W = the winner's totals, size = its serialized size
                 auto choose = [&](bool snap, const Totals<C>& W, uint32_t size, uint32_t narrow) {
@@ -1384,8 +1386,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 if (stage == 1) {
                     // everything is computed in this lane's registers and stored once: a chain of LDS round trips
                     // here would be paid by the 1023 threads waiting at the barrier
-                    const uint32_t t0 = sh.tot[0], t1 = sh.tot[1], t2 = sh.tot[2], t3 = sh.tot[3], t4 = sh.tot[4], t5 = sh.tot[5],
-                                   t6 = sh.tot[6], t7 = sh.tot[7], t8 = sh.tot[8], t9 = sh.tot[9];
+                    const uint32_t t0 = T10[0], t1 = T10[1], t2 = T10[2], t3 = T10[3], t4 = T10[4], t5 = T10[5], t6 = T10[6], t7 = T10[7],
+                                   t8 = T10[8], t9 = T10[9];
                     Totals<C> TS, TL;
                     DacLayout LV{}, LM{};
                     TS.from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);

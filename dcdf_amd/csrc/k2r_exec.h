@@ -108,6 +108,42 @@ struct GpuExec {
         lds_barrier();
     }
 
+    // Split form of reduce<>: reduce_begin leaves the wave totals in sh.wsum (one barrier); totals<>() -- to be called
+    // by every thread at the top of the next phase -- combines them in registers and is valid in thread planner()
+    // only.  Saves the round trip through sh.tot and one barrier when a single thread consumes the sums.
+    template <int NF>
+    __device__ __forceinline__ void reduce_begin() {
+        constexpr int W = NT < 64 ? NT : 64;
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const uint32_t inc = wave_incl_scan(r.sc[f]);
+            if (lane == W - 1) sh.wsum[wave][f] = inc;
+        }
+        lds_barrier();
+    }
+    static constexpr int planner() { return (NT < 64 ? 1 : NT / 64) - 1; }
+    template <int NF>
+    __device__ __forceinline__ void totals(uint32_t (&t)[NF]) {
+        constexpr int NW = NT < 64 ? 1 : NT / 64;
+        if (tid >= 64) {  // other waves have nothing to add (uniform per wave)
+#pragma unroll
+            for (int f = 0; f < NF; f++) t[f] = 0;
+            return;
+        }
+        const int lane = tid;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            int x = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
+            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+            t[f] = (uint32_t)x;
+        }
+    }
+
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
     __device__ __forceinline__ int32_t lds_min(int32_t* p, int32_t v) { return atomicMin(p, v); }
@@ -181,6 +217,16 @@ struct SimExec {
             for (int t = 0; t < NT; t++) run += regs[t].sc[f];
             sh.tot[f] = run;
         }
+    }
+
+    template <int NF>
+    void reduce_begin() {
+        reduce<NF, 0>();
+    }
+    static constexpr int planner() { return 0; }
+    template <int NF>
+    void totals(uint32_t (&t)[NF]) {
+        for (int f = 0; f < NF; f++) t[f] = sh.tot[f];
     }
 
     uint32_t lds_or(uint32_t* p, uint32_t v) {
