@@ -698,7 +698,7 @@ K2R_HD void bitmaps_finish(EX& ex, const BmJob (&J)[NB]) {
             r.sc[f] = sum;
         }
     });
-    ex.template scan<NB>();
+    ex.template scan<NB, false>();
     ex.par([&](int tid, EncRegs& r) {
 #pragma unroll
         for (int f = 0; f < NB; f++) {
@@ -1195,7 +1195,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         auto tbit = [&](int h, uint32_t j) -> uint32_t { return (uint32_t)(C::top_off(h) - C::NBLK) + j; };
 
         // ================= phase 3: own node + (for the first NTOPX threads) one top node each ==========
-        ex.par([&](int tid, EncRegs& r) {
+        // (no barrier of its own: the reduction that follows only takes this phase's per-thread counts)
+        ex.par_nosync([&](int tid, EncRegs& r) {
             uint32_t sI3 = 0, lI3 = 0;
             uint32_t wide = (r.flags >> 28) & 1u;
             Cls lMax, lMin;
@@ -1507,7 +1508,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[3] = d;
             r.sc[4] = e;
         });
-        ex.template scan<5>();
+        ex.template scan<5, false>();  // only the per-thread prefixes are used
         ex.stamp(13);  // scan of the winner's counts
 
         // ================= phase 5: emission of the winner ===============================================
@@ -1557,9 +1558,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 
         // 5b. plane 0 of both Dacs, T (and eqB) bits.  Pass A covers the nodes of heights >= 2; it is instantiated
         // per emission mode (EM_P1 repeats the walk only to place second bytes, so it skips the bitmaps and lists).
-        auto passA = [&](auto mode_tag) {
+        auto passA = [&](auto mode_tag) {  // (no barrier at its end: the caller decides)
           constexpr int MODE = decltype(mode_tag)::value;
-          ex.par([&](int tid, EncRegs& r) {
+          ex.par_nosync([&](int tid, EncRegs& r) {
             uint32_t r0, c0;
             blk_origin(tid, r0, c0);
             const uint64_t pLo = r.pf_lo;
@@ -1692,11 +1693,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         if (use_stash) {
             // ---- a Log whose values all fit two bytes, emitted from the stash: every byte of both Dacs is stored in
             // one visit of each source (EM_ONE), except the second bytes of the few nodes of heights >= 3 ----
+            // Pass A and the two stash passes only write output bytes and OR bits into the LDS bitmaps: nothing one of them
+            // produces is read by another, so a wave runs through all three without waiting for the others.
             passA(EmTag<EM_P0>{});
             ex.stamp(10);
             // one work item per I record: the four height-1 children of an internal height-2 node.  Records are in
             // arrival order; their place in level order comes from the owner's prefixes.
-            ex.par([&](int tid, EncRegs&) {
+            ex.par_nosync([&](int tid, EncRegs&) {
                 const uint32_t offV1 = TT.offV[1], offZ1 = TT.offZ[1], offI1 = TT.offI[1], lt = TT.LT, ne = TT.LT - TT.M0;
                 const uint32_t lv1 = sh.pl.lngV[1], lm1 = sh.pl.lngM[1];
                 for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
@@ -1793,6 +1796,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
             }
             passA(EmTag<EM_LIST>{});
+            ex.barrier();  // pass B consumes the work list pass A built
             ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
             // 5b'. one work item per internal height-2 node (dense, level order): its four height-1 children
             ex.par([&](int tid, EncRegs&) {

@@ -148,8 +148,9 @@ struct GpuExec {
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
     __device__ __forceinline__ int32_t lds_min(int32_t* p, int32_t v) { return atomicMin(p, v); }
 
-    // workgroup exclusive scan of r.sc[0..NF); totals -> sh.tot[0..NF)
-    template <int NF>
+    // workgroup exclusive scan of r.sc[0..NF); totals -> sh.tot[0..NF) unless TOT is false, in which case the prefixes
+    // (registers) are the only result and the closing barrier is saved
+    template <int NF, bool TOT = true>
     __device__ __forceinline__ void scan() {
         constexpr int W = NT < 64 ? NT : 64;    // active lanes per wave
         constexpr int NW = NT < 64 ? 1 : NT / 64;
@@ -174,9 +175,9 @@ struct GpuExec {
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(x, NW - 1);
             const uint32_t base = wave == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane(x, wave - 1);
             r.sc[f] = base + incl[f] - r.sc[f];
-            if (tid == 0) sh.tot[f] = tot;
+            if (TOT && tid == 0) sh.tot[f] = tot;
         }
-        lds_barrier();
+        if (TOT) lds_barrier();
     }
 };
 
@@ -245,7 +246,7 @@ struct SimExec {
         return o;
     }
 
-    template <int NF>
+    template <int NF, bool TOT = true>
     void scan() {
         for (int f = 0; f < NF; f++) {
             uint32_t run = 0;
