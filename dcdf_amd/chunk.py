@@ -96,7 +96,7 @@ def build_batch(arrays, k=2, fractional_bits=0, round=False):
                 continue
             data = C.string_at(e.bytes, e.len)
             mm = np.ctypeslib.as_array(e.minmax, shape=(arrays[i].shape[0], 2)).copy()
-            res.append(MMStruct3Build(Chunk(data), e.len, e.snapshots, e.logs, mm))
+            res.append(MMStruct3Build(Chunk(data, lazy=True), e.len, e.snapshots, e.logs, mm))
     finally:
         L.lib().dcdf_free_encoded(out, C.c_size_t(n))
     return res
@@ -105,17 +105,46 @@ def build_batch(arrays, k=2, fractional_bits=0, round=False):
 class Chunk:
     """An encoded chunk (the serialized `Chunk::write_to` image) opened on the GPU."""
 
-    def __init__(self, data):
+    def __init__(self, data, lazy=False):
+        """`lazy`: upload + parse on the GPU at the first query instead of now (what `build_batch` hands out: a freshly
+        built chunk is usually written out, not queried)."""
         self._bytes = bytes(data)
-        self._h = C.c_void_p()
-        L.check(L.lib().dcdf_chunk_open(self._bytes, C.c_size_t(len(self._bytes)), C.byref(self._h)), "Chunk::read_from")
+        self._handle = None
+        if not lazy:
+            self._open()
+
+    def _open(self):
+        h = C.c_void_p()
+        L.check(L.lib().dcdf_chunk_open(self._bytes, C.c_size_t(len(self._bytes)), C.byref(h)), "Chunk::read_from")
+        self._handle = h
         shp = (C.c_uint32 * 3)()
         enc, fb, nb = C.c_int32(), C.c_uint32(), C.c_uint32()
-        L.check(L.lib().dcdf_chunk_info(self._h, shp, C.byref(enc), C.byref(fb), C.byref(nb)))
+        L.check(L.lib().dcdf_chunk_info(h, shp, C.byref(enc), C.byref(fb), C.byref(nb)))
         self._shape = (int(shp[0]), int(shp[1]), int(shp[2]))
-        self.encoding = int(enc.value)
-        self.fractional_bits = int(fb.value)
-        self.n_blocks = int(nb.value)
+        self._encoding = int(enc.value)
+        self._fractional_bits = int(fb.value)
+        self._n_blocks = int(nb.value)
+
+    @property
+    def _h(self):
+        if self._handle is None:
+            self._open()
+        return self._handle
+
+    @property
+    def encoding(self):
+        self._h
+        return self._encoding
+
+    @property
+    def fractional_bits(self):
+        self._h
+        return self._fractional_bits
+
+    @property
+    def n_blocks(self):
+        self._h
+        return self._n_blocks
 
     # -- construction --------------------------------------------------------------------------
     @staticmethod
@@ -140,12 +169,13 @@ class Chunk:
         return len(self._bytes)
 
     def shape(self):  # chunk.rs:119
+        self._h
         return list(self._shape)
 
     def close(self):
-        if getattr(self, "_h", None):
-            L.lib().dcdf_chunk_close(self._h)
-            self._h = None
+        if getattr(self, "_handle", None):
+            L.lib().dcdf_chunk_close(self._handle)
+            self._handle = None
 
     def __del__(self):
         try:

@@ -3,11 +3,14 @@
 // dcdf_encoder = a device-resident encode session: tile descriptors, per-tile output slots,
 // per-class work queues.  dcdf_chunk_build_batch = upload + session + fetch.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "k2r_launch.h"
@@ -314,51 +317,154 @@ extern "C" void dcdf_free_encoded(dcdf_encoded* out, size_t n) {
     std::free(out);
 }
 
+// Host-side transfer machinery of the host-buffer entry point: two pinned staging buffers filled by a few packing
+// threads while the previous one is in flight on the copy engine (uploads), and drained the same way (downloads).
+namespace {
+
+constexpr size_t kPinBytes = 64u << 20;
+constexpr int kPackThreads = 8;
+
+struct PinRing {
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    hipStream_t stream = nullptr;
+    bool ok = false;
+    std::mutex mu;  // one host-buffer batch at a time uses the ring
+    bool init() {
+        if (ok) return true;
+        for (int i = 0; i < 2; i++) {
+            if (hipHostMalloc(&buf[i], kPinBytes, hipHostMallocDefault) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+    bool wait(int b) {
+        if (busy[b] && hipEventSynchronize(ev[b]) != hipSuccess) return false;
+        busy[b] = false;
+        return true;
+    }
+};
+PinRing& pin_ring() {
+    static PinRing r;
+    return r;
+}
+
+// runs f(0..n) on up to kPackThreads threads
+template <class F>
+void parallel_for(size_t n, F&& f) {
+    const size_t nt = std::min<size_t>(kPackThreads, n);
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    for (size_t t = 0; t < nt; t++)
+        th.emplace_back([&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+// dense copy of a (possibly strided) host tile (mmbuffer.rs:517-522 tile slices)
+void pack_tile(const dcdf_tile_desc& t, uint8_t* d) {
+    const size_t es = elem_size(t.dtype);
+    const uint8_t* src = (const uint8_t*)t.base;
+    const bool contiguous = t.stride_c == 1 && t.stride_r == (int64_t)t.cols && t.stride_t == (int64_t)t.rows * t.cols;
+    if (contiguous) {
+        std::memcpy(d, src, (size_t)t.instants * t.rows * t.cols * es);
+        return;
+    }
+    for (uint32_t a = 0; a < t.instants; a++)
+        for (uint32_t r = 0; r < t.rows; r++) {
+            const uint8_t* row = src + ((int64_t)a * t.stride_t + (int64_t)r * t.stride_r) * (int64_t)es;
+            if (t.stride_c == 1) {
+                std::memcpy(d, row, (size_t)t.cols * es);
+                d += (size_t)t.cols * es;
+            } else {
+                for (uint32_t c = 0; c < t.cols; c++, d += es) std::memcpy(d, row + (int64_t)c * t.stride_c * (int64_t)es, es);
+            }
+        }
+}
+
+}  // namespace
+
 static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dcdf_encoded* out) {
     // tiles[0..n) fit the staging budget; host tiles are packed contiguously and uploaded
     std::vector<dcdf_tile_desc> dev(tiles, tiles + n);
     DevBuf stage;
+    PinRing& ring = pin_ring();
+    std::unique_lock<std::mutex> ring_lock(ring.mu, std::defer_lock);
     if (mem == DCDF_MEM_HOST) {
+        ring_lock.lock();
+        if (!ring.init()) return DCDF_ERR_NOMEM;
         uint64_t total = 0;
-        std::vector<uint64_t> off(n);
+        std::vector<uint64_t> off(n), bytes(n, 0);
         for (size_t i = 0; i < n; i++) {
             off[i] = total;
             const dcdf_tile_desc& t = tiles[i];
             if (!t.base || t.instants == 0 || t.rows == 0 || t.cols == 0) continue;
-            total += ((uint64_t)t.instants * t.rows * t.cols * elem_size(t.dtype) + 255) & ~255ull;
+            if (t.dtype != DCDF_I32 && t.dtype != DCDF_I64 && t.dtype != DCDF_F32 && t.dtype != DCDF_F64) continue;
+            bytes[i] = (uint64_t)t.instants * t.rows * t.cols * elem_size(t.dtype);
+            total += (bytes[i] + 255) & ~255ull;
         }
         K2R_HIP(stage.alloc(total));
-        std::vector<uint8_t> pack;
-        for (size_t i = 0; i < n; i++) {
-            const dcdf_tile_desc& t = tiles[i];
-            if (!t.base || t.instants == 0 || t.rows == 0 || t.cols == 0) continue;
-            if (t.dtype != DCDF_I32 && t.dtype != DCDF_I64 && t.dtype != DCDF_F32 && t.dtype != DCDF_F64) continue;
-            const size_t es = elem_size(t.dtype);
-            const uint64_t bytes = (uint64_t)t.instants * t.rows * t.cols * es;
-            const uint8_t* src = (const uint8_t*)t.base;
-            const bool contiguous = t.stride_c == 1 && t.stride_r == (int64_t)t.cols &&
-                                    t.stride_t == (int64_t)t.rows * t.cols;
-            if (!contiguous) {  // gather the strided view (mmbuffer.rs:517-522 tile slices)
-                pack.resize(bytes);
-                uint8_t* d = pack.data();
-                for (uint32_t a = 0; a < t.instants; a++)
-                    for (uint32_t r = 0; r < t.rows; r++) {
-                        const uint8_t* row = src + ((int64_t)a * t.stride_t + (int64_t)r * t.stride_r) * (int64_t)es;
-                        if (t.stride_c == 1) {
-                            std::memcpy(d, row, (size_t)t.cols * es);
-                            d += (size_t)t.cols * es;
-                        } else {
-                            for (uint32_t c = 0; c < t.cols; c++, d += es)
-                                std::memcpy(d, row + (int64_t)c * t.stride_c * (int64_t)es, es);
-                        }
-                    }
-                src = pack.data();
+        // fills: runs of tiles whose staged range fits one pinned buffer (a tile larger than that goes alone, in pieces)
+        size_t i = 0;
+        int fill = 0;
+        while (i < n) {
+            if (bytes[i] == 0) {
+                i++;
+                continue;
             }
-            K2R_HIP(hipMemcpy(stage.as<uint8_t>() + off[i], src, bytes, hipMemcpyHostToDevice));
-            dev[i].base = stage.as<uint8_t>() + off[i];
-            dev[i].stride_c = 1;
-            dev[i].stride_r = t.cols;
-            dev[i].stride_t = (int64_t)t.rows * t.cols;
+            const int b = fill & 1;
+            if (!ring.wait(b)) return DCDF_ERR_NO_DEVICE;
+            if (bytes[i] > kPinBytes) {  // oversize tile: dense temporary, then piecewise through the ring
+                std::vector<uint8_t> tmp(bytes[i]);
+                pack_tile(tiles[i], tmp.data());
+                for (uint64_t o = 0; o < bytes[i]; o += kPinBytes) {
+                    const int bb = fill & 1;
+                    if (!ring.wait(bb)) return DCDF_ERR_NO_DEVICE;
+                    const size_t len = (size_t)std::min<uint64_t>(kPinBytes, bytes[i] - o);
+                    std::memcpy(ring.buf[bb], tmp.data() + o, len);
+                    K2R_HIP(hipMemcpyAsync(stage.as<uint8_t>() + off[i] + o, ring.buf[bb], len, hipMemcpyHostToDevice, ring.stream));
+                    K2R_HIP(hipEventRecord(ring.ev[bb], ring.stream));
+                    ring.busy[bb] = true;
+                    fill++;
+                }
+                i++;
+                continue;
+            }
+            size_t j = i;
+            const uint64_t base_off = off[i];
+            while (j < n && (bytes[j] == 0 || off[j] + bytes[j] - base_off <= kPinBytes)) j++;
+            uint8_t* pb = (uint8_t*)ring.buf[b];
+            parallel_for(j - i, [&](size_t q) {
+                const size_t ti = i + q;
+                if (bytes[ti]) pack_tile(tiles[ti], pb + (off[ti] - base_off));
+            });
+            const uint64_t len = (j < n ? off[j] : total) - base_off;
+            K2R_HIP(hipMemcpyAsync(stage.as<uint8_t>() + base_off, pb, std::min<uint64_t>(len, kPinBytes), hipMemcpyHostToDevice, ring.stream));
+            K2R_HIP(hipEventRecord(ring.ev[b], ring.stream));
+            ring.busy[b] = true;
+            fill++;
+            i = j;
+        }
+        if (!ring.wait(0) || !ring.wait(1)) return DCDF_ERR_NO_DEVICE;
+        for (size_t q = 0; q < n; q++) {
+            if (!bytes[q]) continue;
+            const dcdf_tile_desc& t = tiles[q];
+            dev[q].base = stage.as<uint8_t>() + off[q];
+            dev[q].stride_c = 1;
+            dev[q].stride_r = t.cols;
+            dev[q].stride_t = (int64_t)t.rows * t.cols;
         }
     }
     dcdf_encoder* e = nullptr;
@@ -369,6 +475,7 @@ static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dc
     if (rc != DCDF_OK) return rc;
     std::vector<int64_t> mm(e->minmax_total);
     if (e->minmax_total) K2R_HIP(hipMemcpy(mm.data(), e->d_minmax.p, e->minmax_total * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> lens(n, 0);
     for (size_t i = 0; i < n; i++) {
         int32_t st;
         uint64_t len;
@@ -384,11 +491,52 @@ static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dc
         out[i].bytes = (uint8_t*)std::malloc(len ? len : 1);
         out[i].minmax = (int64_t*)std::malloc(16ull * tiles[i].instants);
         if (!out[i].bytes || !out[i].minmax) return DCDF_ERR_NOMEM;
-        rc = dcdf_encoder_fetch(e, i, out[i].bytes, len);
-        if (rc != DCDF_OK) return rc;
+        lens[i] = len;
         out[i].len = len;
         std::memcpy(out[i].minmax, mm.data() + e->minmax_off[i], 16ull * tiles[i].instants);
     }
+    // encoded bytes: device slots -> pinned buffer (async, one copy per tile) -> the caller's buffers (threads)
+    if (!ring_lock.owns_lock()) ring_lock.lock();
+    if (!ring.init()) return DCDF_ERR_NOMEM;
+    size_t i = 0;
+    int fill = 0;
+    std::vector<size_t> pend[2];
+    std::vector<uint64_t> pend_off[2];
+    auto drain = [&](int b) -> bool {
+        if (!ring.wait(b)) return false;
+        const uint8_t* pb = (const uint8_t*)ring.buf[b];
+        parallel_for(pend[b].size(), [&](size_t q) { std::memcpy(out[pend[b][q]].bytes, pb + pend_off[b][q], lens[pend[b][q]]); });
+        pend[b].clear();
+        pend_off[b].clear();
+        return true;
+    };
+    while (i < n) {
+        if (lens[i] == 0) {
+            i++;
+            continue;
+        }
+        if (lens[i] > kPinBytes) {  // oversize result: plain copy
+            K2R_HIP(hipMemcpy(out[i].bytes, e->args[i].out, lens[i], hipMemcpyDeviceToHost));
+            i++;
+            continue;
+        }
+        const int b = fill & 1;
+        if (!drain(b)) return DCDF_ERR_NO_DEVICE;
+        uint64_t used = 0;
+        while (i < n && (lens[i] == 0 || (lens[i] <= kPinBytes && used + lens[i] <= kPinBytes))) {
+            if (lens[i]) {
+                K2R_HIP(hipMemcpyAsync((uint8_t*)ring.buf[b] + used, e->args[i].out, lens[i], hipMemcpyDeviceToHost, ring.stream));
+                pend[b].push_back(i);
+                pend_off[b].push_back(used);
+                used += (lens[i] + 63) & ~63ull;
+            }
+            i++;
+        }
+        K2R_HIP(hipEventRecord(ring.ev[b], ring.stream));
+        ring.busy[b] = true;
+        fill++;
+    }
+    if (!drain(0) || !drain(1)) return DCDF_ERR_NO_DEVICE;
     return DCDF_OK;
 }
 
