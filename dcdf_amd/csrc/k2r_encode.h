@@ -8,10 +8,10 @@
 //
 // Parallel formulation (not how the reference does it; results are bit-identical):
 //  * thread `tid` owns the 8x8 cell block whose Morton index is `tid` (row bit above col
-//    bit == the reference's child order i*k+j, snapshot.rs:468-474).  Its 64 cells live in
-//    registers in Morton order, so heights 0..3 of the quadtree are thread-local and level
-//    order == (tid, local Morton) order at every level.
-//  * heights 4..H live in LDS ("top" arrays), built bottom-up with H-3 barriers.
+//    bit == the reference's child order i*k+j, snapshot.rs:468-474).  The block is streamed as four 4x4
+//    sub-blocks, so heights 0..3 of the quadtree are thread-local and level order == (tid, local Morton)
+//    order at every level.
+//  * heights 4..H live in LDS ("top" arrays), built bottom-up.
 //  * "internal" is a LOCAL predicate.  Snapshot: P(n) = min(n) != max(n) (snapshot.rs:133).
 //    Log: P(n) = min_t != max_t and not equal(n) (log.rs:137-152).  Both are monotone
 //    (P(child) => P(parent)), so a node is visited iff P(parent) and is internal iff P(n):
@@ -21,9 +21,14 @@
 //    offV[h] + 4*r (cf. the decoder's 1 + rank(T, i)*k^2, snapshot.rs:177).
 //  * sizes are functions of counts only, so both candidates (Snapshot
 //    and Log, chunk.rs:57-60) are only COUNTED; the winner of chunk.rs:62 alone is emitted.
-//  * DAC planes >= 1 are rare: values needing more than one byte are appended to a per-
-//    workgroup overflow list and placed by rank over the previous plane's continuation
-//    bitmap (exactly the decoder's hop, dac.rs:83-90).
+//  * a Log is emitted from an LDS "stash" of what phase 1 saw below height 2 (no second read of the
+//    input); when all its values fit two bytes, phase 1 also counts the second bytes per level, so
+//    that every byte of both Dacs is placed in a single visit of each stash record (EM_ONE).
+//  * Snapshots (1 instant in ~32) and logs with wider values take the general path: the tile is
+//    re-read by work-list passes, values longer than a byte go to an overflow list and are placed
+//    by rank over the previous plane's continuation bitmap (the decoder's hop, dac.rs:83-90).
+//  * the block's snapshot instant, compared with every later instant of the block, is kept as a
+//    compact uint16 copy in global scratch when its range allows.
 //
 // Value-range contract of this fast path: |stored value| < 2^30 (int32 arithmetic is then
 // exact and every zig-zag code fits 4 bytes).  Tiles outside it report ST_UNSUPPORTED.
@@ -130,9 +135,6 @@ constexpr int cell_m(int dr, int dc) {
 // Morton index m (0..63) -> (dr,dc)
 constexpr int m_dr(int m) { return (((m >> 5) & 1) << 2) | (((m >> 3) & 1) << 1) | ((m >> 1) & 1); }
 constexpr int m_dc(int m) { return (((m >> 4) & 1) << 2) | (((m >> 2) & 1) << 1) | (m & 1); }
-
-// 4-entry register array read with a runtime index (select chain; keeps rolled loops off scratch memory)
-K2R_HD int32_t sel4(const int32_t (&a)[4], int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
 
 K2R_HD int32_t min4(int32_t a, int32_t b, int32_t c, int32_t d) {
     int32_t x = a < b ? a : b, y = c < d ? c : d;
@@ -467,18 +469,6 @@ K2R_HD DacLayout dac_layout(uint32_t base, uint32_t n0, uint32_t n1, uint32_t n2
     return L;
 }
 
-// number of set bits in positions [lo, hi) of a small LDS bitset
-K2R_HD uint32_t bits_count(const uint32_t* w, uint32_t lo, uint32_t hi) {
-    uint32_t n = 0;
-    for (uint32_t i = lo >> 5; i <= ((hi + 31) >> 5) && (i << 5) < hi; i++) {
-        uint32_t x = w[i];
-        const uint32_t b0 = i << 5;
-        if (lo > b0) x &= 0xffffffffu << (lo - b0);
-        if (hi < b0 + 32) x &= (hi > b0) ? (0xffffffffu >> (b0 + 32 - hi)) : 0u;
-        n += popc32(x);
-    }
-    return n;
-}
 K2R_HD bool bit_test(const uint32_t* w, uint32_t b) { return (w[b >> 5] >> (b & 31)) & 1u; }
 
 template <class C>
@@ -609,9 +599,6 @@ enum : uint32_t {
 // bit p lives in word p/32 at position 31-(p%32)  (bitmap.rs:176-183)
 template <class EX>
 K2R_HD void bm_set(EX& ex, uint32_t* bm, uint32_t p) {
-#ifdef K2R_X_NOATOMIC
-    return;
-#endif
     ex.lds_or(&bm[p >> 5], 0x80000000u >> (p & 31));
 }
 // OR a run of `len` (1..32) bits starting at bit position p; bits are right-aligned in `bits`,
@@ -619,9 +606,6 @@ K2R_HD void bm_set(EX& ex, uint32_t* bm, uint32_t p) {
 template <class EX>
 K2R_HD void bm_or_run(EX& ex, uint32_t* bm, uint32_t p, uint32_t len, uint32_t bits) {
     if (len == 0 || bits == 0) return;
-#ifdef K2R_X_NOATOMIC
-    return;
-#endif
     const uint64_t v = (uint64_t)bits << (64 - len);  // left-aligned in 64
     const uint32_t sh = p & 31;
     const uint64_t w = v >> sh;  // occupies bits of words (p>>5) and (p>>5)+1
@@ -741,15 +725,13 @@ struct DacSink {
 // Emission modes.
 //   EM_LIST : one pass; plane-0 bytes are stored, values longer than a byte are appended to the overflow list and
 //             placed by dac_finish (any number of planes).
-//   EM_P0 / EM_P1 : two passes over the same sources for Dacs known to have at most two planes (every value
-//             < 2^16 after zig-zag).  EM_P0 stores the plane-0 bytes and sets the continuation bits; once the
-//             bitmap's rank prefixes exist, EM_P1 revisits the sources and stores byte 1 of every long value at
-//             rank1(continuation, pos) -- the decoder's own hop (dac.rs:83-90) -- with no list and no atomics.
-//             Used for the few nodes of heights >= 3.
+//   EM_P0   : for the few nodes of heights >= 3 of a two-plane Dac: plane-0 byte and continuation bit now; the second
+//             byte is placed later, once the bitmap's rank prefixes exist, at rank1(continuation, pos) -- the decoder's
+//             own hop (dac.rs:83-90).
 //   EM_ONE  : one pass, for the same two-plane Dacs, when the caller already knows `lpos` = that rank (phase 1
 //             counted the long values per level and a scan turned the counts into positions): plane-0 bytes,
 //             continuation bits and second bytes are all stored at once.
-enum : int { EM_LIST = 0, EM_P0 = 1, EM_P1 = 2, EM_ONE = 3 };
+enum : int { EM_LIST = 0, EM_P0 = 1, EM_ONE = 3 };
 template <int V>
 struct EmTag {
     static constexpr int value = V;
@@ -777,13 +759,6 @@ template <int WHICH, int MODE = EM_LIST, class EX>
 K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid, uint32_t lpos = 0) {
     pos = guard_pos(ex, pos, 1, d.n0, d.code);
     uint32_t* const bm0 = WHICH ? ex.sh.bmM[0] : ex.sh.bmV0;
-    if (MODE == EM_P1) {
-        if (zz > 0xffu) {
-            const uint32_t q = guard_pos(ex, bm_rank(bm0, d.pref, pos), 1, d.n1, d.code + 1);
-            gstore8(d.plane1 + q, (uint8_t)(zz >> 8));
-        }
-        return;
-    }
     gstore8(d.plane0 + pos, (uint8_t)zz);
     if (zz > 0xffu) {
         bm_set(ex, bm0, pos);
@@ -802,20 +777,6 @@ K2R_HD void emit4(EX& ex, const DacSink& d, uint32_t pos, uint32_t z0, uint32_t 
                   uint32_t lpos = 0) {
     pos = guard_pos(ex, pos, 4, d.n0, d.code);
     uint32_t* const bm0 = WHICH ? ex.sh.bmM[0] : ex.sh.bmV0;
-    if (MODE == EM_P1) {
-        if ((z0 | z1 | z2 | z3) > 0xffu) {
-            uint32_t q = bm_rank(bm0, d.pref, pos);
-            const uint32_t z[4] = {z0, z1, z2, z3};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (z[i] > 0xffu) {
-                    gstore8(d.plane1 + guard_pos(ex, q, 1, d.n1, d.code + 1), (uint8_t)(z[i] >> 8));
-                    q++;
-                }
-            }
-        }
-        return;
-    }
     gstore32u(d.plane0 + pos, (z0 & 0xffu) | ((z1 & 0xffu) << 8) | ((z2 & 0xffu) << 16) | (z3 << 24));
     if ((z0 | z1 | z2 | z3) > 0xffu) {
         if (MODE == EM_P0 || MODE == EM_ONE) {
@@ -1557,7 +1518,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                             io + ex.uni(DM.by_off[1]), sh.prefM};
 
         // 5b. plane 0 of both Dacs, T (and eqB) bits.  Pass A covers the nodes of heights >= 2; it is instantiated
-        // per emission mode (EM_P1 repeats the walk only to place second bytes, so it skips the bitmaps and lists).
+        // per emission mode.
         auto passA = [&](auto mode_tag) {  // (no barrier at its end: the caller decides)
           constexpr int MODE = decltype(mode_tag)::value;
           ex.par_nosync([&](int tid, EncRegs& r) {
