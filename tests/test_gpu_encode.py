@@ -195,3 +195,19 @@ def test_int32_rows_value_range_contract(dc):
     a[1, 9, 9] = 2 ** 30 - 1
     a[0, 1, 1] = -(2 ** 30)
     assert_same(dc, [a])
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.float32, np.float64])
+def test_row_loader_selection_aligned_and_not(dc, dtype):
+    """Every element type has a 16-byte row loader for aligned, unit-stride tiles and falls back to the generic loader
+    otherwise (misaligned base, odd row stride, transposed view): all of them must give the oracle's bytes."""
+    from dcdf_amd import synth
+    fb = 3 if np.dtype(dtype).kind == "f" else 0
+    big = synth.cells(11, 0, 5, 0, 66, 0, 70, np.int32)
+    big = (big / 8.0).astype(dtype) if fb else big.astype(dtype)
+    aligned = np.ascontiguousarray(big[:, :64, :64])
+    assert aligned.ctypes.data % 16 == 0
+    shifted = big[:, 1:65, 1:65]           # base not 16-byte aligned, row stride 70
+    odd = np.ascontiguousarray(big[:, :64, :67])[:, :, :64]  # row stride 67 elements
+    transposed = np.ascontiguousarray(big[:, :64, :64].transpose(0, 2, 1)).transpose(0, 2, 1)  # column stride != 1
+    assert_same(dc, [aligned, shifted, odd, transposed], fractional_bits=fb)
