@@ -1209,7 +1209,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[6] = wide;
         });
         ex.stamp(2);  // phase 3: own/top nodes
-        ex.template reduce_begin<10>();  // the sums are combined by the planning thread itself (phase 4)
+        // one scan serves both the totals the planner needs and the prefixes emission needs (of both candidates:
+        // the winner's are picked once it is known); it is finished inside the planning phase
+        ex.template scan_begin<10>();
         ex.stamp(3);  // totals of the 4 packed fields
 
         // Exact byte classes of EVERY value of one candidate (0 = snapshot, 1 = log): a second streaming pass over
@@ -1322,7 +1324,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         auto plan = [&](const int stage) {
             ex.par([&](int tid, EncRegs&) {
                 uint32_t T10[10];
-                if (stage == 1) ex.template totals<10>(T10);  // every thread takes part; the sums land in thread planner()
+                if (stage == 1) ex.template scan_finish<10>(T10);  // every thread: its prefixes; the totals for the planner
                 if (tid != (stage == 1 ? EX::planner() : 0)) return;
                 auto& pl = sh.pl;
                 // the decision: W = the winner's totals, size = its serialized size
@@ -1458,20 +1460,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         uint8_t* const io = out + off;  // first byte of this Snapshot / Log
         n_stash += use_stash ? 1u : 0u;
         ex.stamp(12);  // sizes + heuristic (wave-uniform arithmetic, lazy class passes)
-        // exclusive prefixes of the winner's internal counts (positions)
-        ex.par_nosync([&](int, EncRegs& r) {
-            const uint32_t a = as_snapshot ? r.sc[0] : r.sc[3];                      // I1 | I2 << 16
-            const uint32_t b = as_snapshot ? (r.sc[1] & 0xffffu) : (r.sc[1] >> 16);  // I3
-            const uint32_t c = r.sc[7], d = r.sc[8], e = r.sc[9];                    // second bytes per level (logs)
-            r.sc[0] = a;
-            r.sc[1] = b;
-            r.sc[2] = c;
-            r.sc[3] = d;
-            r.sc[4] = e;
-        });
-        ex.template scan<5, false>();  // only the per-thread prefixes are used
-        ex.stamp(13);  // scan of the winner's counts
-
         // ================= phase 5: emission of the winner ===============================================
         // 5a. clear bitmaps, save prefixes, header
         const uint32_t WTn = (ex.uni(TT.LT) + 31) / 32, WVn = (ex.uni(TT.N0) + 31) / 32, WMn = (ex.uni(TT.M0) + 31) / 32;
@@ -1482,11 +1470,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
             for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV0[w] = 0;
             for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
-            r.pf_lo = (uint64_t)r.sc[0] | ((uint64_t)r.sc[1] << 30);  // the lo pack of unpackI
-            r.pf_l2 = (r.sc[3] >> 16) | (r.sc[4] & 0xffff0000u);       // second bytes before this block's height-2 group: Lmax | Lmin << 16
-            sh.pfx[0][tid] = r.sc[0];
-            sh.pfx[1][tid] = r.sc[2];
-            sh.pfx[2][tid] = (r.sc[3] & 0xffffu) | (r.sc[4] << 16);
+            // exclusive prefixes of the winner's counts (phase 3 scanned both candidates')
+            const uint32_t pI12 = as_snapshot ? r.sc[0] : r.sc[3];                      // I1 | I2 << 16
+            const uint32_t pI3 = as_snapshot ? (r.sc[1] & 0xffffu) : (r.sc[1] >> 16);
+            const uint32_t pL0 = r.sc[7], pL12 = r.sc[8], pM12 = r.sc[9];               // second bytes per level (logs)
+            r.pf_lo = (uint64_t)pI12 | ((uint64_t)pI3 << 30);  // the lo pack of unpackI
+            r.pf_l2 = (pL12 >> 16) | (pM12 & 0xffff0000u);     // second bytes before this block's height-2 group: Lmax | Lmin << 16
+            sh.pfx[0][tid] = pI12;
+            sh.pfx[1][tid] = pL0;
+            sh.pfx[2][tid] = (pL12 & 0xffffu) | (pM12 << 16);
             if (tid <= C::TBW) {  // rank prefix over the winner's top-node flags (<= 12 words)
                 const uint32_t* const tbw = as_snapshot ? sh.tbS : sh.tbL;
                 uint32_t run = 0;

@@ -108,11 +108,12 @@ struct GpuExec {
         lds_barrier();
     }
 
-    // Split form of reduce<>: reduce_begin leaves the wave totals in sh.wsum (one barrier); totals<>() -- to be called
-    // by every thread at the top of the next phase -- combines them in registers and is valid in thread planner()
-    // only.  Saves the round trip through sh.tot and one barrier when a single thread consumes the sums.
+    // Split form of scan<>, for a scan whose totals are consumed by one thread and whose prefixes are needed one
+    // phase later: scan_begin turns r.sc[f] into wave-local exclusive prefixes and leaves the wave totals in sh.wsum
+    // (one barrier); scan_finish -- called by every thread at the top of the next phase -- adds the wave bases and
+    // returns the workgroup totals (in every thread).  No round trip through sh.tot, no second barrier.
     template <int NF>
-    __device__ __forceinline__ void reduce_begin() {
+    __device__ __forceinline__ void scan_begin() {
         constexpr int W = NT < 64 ? NT : 64;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,19 +121,16 @@ struct GpuExec {
         for (int f = 0; f < NF; f++) {
             const uint32_t inc = wave_incl_scan(r.sc[f]);
             if (lane == W - 1) sh.wsum[wave][f] = inc;
+            r.sc[f] = inc - r.sc[f];
         }
         lds_barrier();
     }
-    static constexpr int planner() { return (NT < 64 ? 1 : NT / 64) - 1; }
+    static constexpr int planner() { return 0; }
     template <int NF>
-    __device__ __forceinline__ void totals(uint32_t (&t)[NF]) {
+    __device__ __forceinline__ void scan_finish(uint32_t (&tot)[NF]) {
         constexpr int NW = NT < 64 ? 1 : NT / 64;
-        if (tid >= 64) {  // other waves have nothing to add (uniform per wave)
-#pragma unroll
-            for (int f = 0; f < NF; f++) t[f] = 0;
-            return;
-        }
-        const int lane = tid;
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             int x = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
@@ -140,7 +138,8 @@ struct GpuExec {
             x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
             x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
             x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
-            t[f] = (uint32_t)x;
+            tot[f] = (uint32_t)__builtin_amdgcn_readlane(x, NW - 1);
+            r.sc[f] += wave == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane(x, wave - 1);
         }
     }
 
@@ -221,12 +220,12 @@ struct SimExec {
     }
 
     template <int NF>
-    void reduce_begin() {
-        reduce<NF, 0>();
+    void scan_begin() {
+        scan<NF, true>();
     }
     static constexpr int planner() { return 0; }
     template <int NF>
-    void totals(uint32_t (&t)[NF]) {
+    void scan_finish(uint32_t (&t)[NF]) {
         for (int f = 0; f < NF; f++) t[f] = sh.tot[f];
     }
 
