@@ -1324,7 +1324,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         auto plan = [&](const int stage) {
             ex.par([&](int tid, EncRegs&) {
                 uint32_t T10[10];
-                if (stage == 1) ex.template scan_finish<10>(T10);  // every thread: its prefixes; the totals for the planner
+                if (stage == 1) {
+                    ex.template scan_finish<10>(T10);  // every thread: its prefixes; the totals for the planner
+                    // the emission bitmaps are cleared here, while all threads but the planner would only wait
+                    for (uint32_t w = (uint32_t)tid; w <= (uint32_t)C::WT; w += NT) {
+                        sh.bmT[w] = 0;
+                        sh.bmE[w] = 0;
+                        sh.bmM[0][w] = 0;
+                    }
+                    for (uint32_t w = (uint32_t)tid; w <= (uint32_t)C::WV; w += NT) sh.bmV0[w] = 0;
+                }
                 if (tid != (stage == 1 ? EX::planner() : 0)) return;
                 auto& pl = sh.pl;
                 // the decision: W = the winner's totals, size = its serialized size
@@ -1461,15 +1470,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         n_stash += use_stash ? 1u : 0u;
         ex.stamp(12);  // sizes + heuristic (wave-uniform arithmetic, lazy class passes)
         // ================= phase 5: emission of the winner ===============================================
-        // 5a. clear bitmaps, save prefixes, header
-        const uint32_t WTn = (ex.uni(TT.LT) + 31) / 32, WVn = (ex.uni(TT.N0) + 31) / 32, WMn = (ex.uni(TT.M0) + 31) / 32;
+        // 5a. save prefixes, header (the bitmaps were cleared during planning)
         ex.par([&](int tid, EncRegs& r) {
-            for (uint32_t w = (uint32_t)tid; w <= WTn; w += NT) {
-                sh.bmT[w] = 0;
-                sh.bmE[w] = 0;
-            }
-            for (uint32_t w = (uint32_t)tid; w <= WVn; w += NT) sh.bmV0[w] = 0;
-            for (uint32_t w = (uint32_t)tid; w <= WMn; w += NT) sh.bmM[0][w] = 0;
             // exclusive prefixes of the winner's counts (phase 3 scanned both candidates')
             const uint32_t pI12 = as_snapshot ? r.sc[0] : r.sc[3];                      // I1 | I2 << 16
             const uint32_t pI3 = as_snapshot ? (r.sc[1] & 0xffffu) : (r.sc[1] >> 16);
