@@ -1334,7 +1334,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                     for (uint32_t w = (uint32_t)tid; w <= (uint32_t)C::WV; w += NT) sh.bmV0[w] = 0;
                 }
-                if (tid != (stage == 1 ? EX::planner() : 0)) return;
+                // Stage 1 runs on two lanes of wave 0 at once where it can -- lane 0 plans the snapshot candidate, lane 1
+                // the log candidate, the same instructions on different data -- and exchanges the two sizes with readlane;
+                // the sequential context (and a 1-thread workgroup) lets thread 0 do both in turn.
+                constexpr bool kTwoLanes = !EX::kSim && NT >= 2;
+                if (tid >= (stage == 1 && kTwoLanes ? 2 : 1)) return;
                 auto& pl = sh.pl;
                 // the decision: W = the winner's totals, size = its serialized size
                 auto choose = [&](bool snap, const Totals<C>& W, uint32_t size, uint32_t narrow) {
@@ -1357,52 +1361,81 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     sh.ttR[H + 1] = rr;
                 };
                 if (stage == 1) {
-                    // everything is computed in this lane's registers and stored once: a chain of LDS round trips
-                    // here would be paid by the 1023 threads waiting at the barrier
+                    // everything is computed in registers and stored once: a chain of LDS round trips here would be paid by
+                    // the whole workgroup waiting at the barrier
                     const uint32_t t0 = T10[0], t1 = T10[1], t2 = T10[2], t3 = T10[3], t4 = T10[4], t5 = T10[5], t6 = T10[6], t7 = T10[7],
                                    t8 = T10[8], t9 = T10[9];
-                    Totals<C> TS, TL;
-                    DacLayout LV{}, LM{};
-                    TS.from((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30), t2);
-                    uint32_t need = 0, narrow = 0, log_size = 0, eq_off = 0;
-                    if (have_s) {
-                        TL.from((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30), t4);
-                        narrow = t6 == 0 ? 1u : 0u;
-                        eq_off = 13 + bitmap_size(TL.LT);
-                        // second bytes come in level order too: first those of heights >= 3, then height 2, 1, 0
-                        const uint32_t lv2 = t5 & 0xffffu, lv1 = lv2 + (t8 >> 16), lv0 = lv1 + (t8 & 0xffffu);
-                        const uint32_t lm2 = t5 >> 16, lm1 = lm2 + (t9 >> 16);
+                    const uint32_t narrow = (have_s && t6 == 0) ? 1u : 0u;
+                    // second bytes come in level order too: first those of heights >= 3, then height 2, 1, 0
+                    const uint32_t lv2 = t5 & 0xffffu, lv1 = lv2 + (t8 >> 16), lv0 = lv1 + (t8 & 0xffffu);
+                    const uint32_t lm2 = t5 >> 16, lm1 = lm2 + (t9 >> 16);
+                    // candidate c (0 snapshot, 1 log): level offsets, Dac layouts (the snapshot's with one byte per value:
+                    // a lower bound; the log's with the inline "> 1 byte" counts, exact when narrow), serialized size
+                    auto cand = [&](uint32_t c, Totals<C>& T, DacLayout& V, DacLayout& M, uint32_t& eo) {
+                        T.from(c == 0 ? ((uint64_t)t0 | ((uint64_t)(t1 & 0xffffu) << 30)) : ((uint64_t)t3 | ((uint64_t)(t1 >> 16) << 30)),
+                               c == 0 ? t2 : t4);
+                        eo = 13 + bitmap_size(T.LT);
+                        const uint32_t vbase = c == 0 ? eo : eo + bitmap_size(T.LT - T.M0);
+                        const bool counts = c == 1 && narrow;
+                        V = dac_layout(vbase, T.N0, counts ? lv0 + t7 : 0u, 0, 0);
+                        M = dac_layout(V.end, T.M0, counts ? lm1 + (t9 & 0xffffu) : 0u, 0, 0);
+                    };
+                    uint32_t snap_lb, log_size, eq_off;
+                    Totals<C> TW;  // the log candidate's totals, in the registers of the thread that may have to choose() it
+                    bool i_hold_log;
+                    if (kTwoLanes) {
+                        DacLayout V, M;
+                        uint32_t eo;
+                        cand((uint32_t)tid, TW, V, M, eo);
+                        if (tid == 0 || have_s) {
+                            pl.T[tid] = TW;
+                            pl.V[tid] = V;
+                            pl.M[tid] = M;
+                        }
+                        snap_lb = ex.lane_value(M.end, 0);
+                        log_size = have_s ? ex.lane_value(M.end, 1) : 0u;
+                        eq_off = have_s ? ex.lane_value(eo, 1) : 0u;
+                        i_hold_log = tid == 1;
+                    } else {
+                        Totals<C> TS;
+                        DacLayout SV, SM, LV{}, LM{};
+                        uint32_t eo0, eo1 = 0;
+                        cand(0, TS, SV, SM, eo0);
+                        pl.T[0] = TS;
+                        pl.V[0] = SV;
+                        pl.M[0] = SM;
+                        if (have_s) {
+                            cand(1, TW, LV, LM, eo1);
+                            pl.T[1] = TW;
+                            pl.V[1] = LV;
+                            pl.M[1] = LM;
+                        }
+                        snap_lb = SM.end;
+                        log_size = have_s ? LM.end : 0u;
+                        eq_off = eo1;
+                        i_hold_log = true;
+                    }
+                    uint32_t need = 0;
+                    if (have_s && !narrow) {
+                        need = 1;  // some log value may need 3+ bytes: count exactly first
+                        log_size = 0;
+                    } else if (!have_s || cap254 || snap_lb <= log_size) {
+                        need = 2;  // the snapshot may win (or must be taken): count its byte classes exactly
+                    } else if (i_hold_log) {
+                        choose(false, TW, log_size, narrow);  // log.rs:95-97 vs snapshot.rs:87-92: the log wins
+                    }
+                    if (tid == 0) {
                         pl.lngV[0] = lv0;
                         pl.lngV[1] = lv1;
                         pl.lngV[2] = lv2;
                         pl.lngM[1] = lm1;
                         pl.lngM[2] = lm2;
-                        if (narrow) {  // only "> 1 byte" counts are kept inline
-                            LV = dac_layout(eq_off + bitmap_size(TL.LT - TL.M0), TL.N0, lv0 + t7, 0, 0);
-                            LM = dac_layout(LV.end, TL.M0, lm1 + (t9 & 0xffffu), 0, 0);
-                            log_size = LM.end;  // log.rs:95-97
-                        } else {
-                            need = 1;  // some log value may need 3+ bytes: count exactly first
-                        }
-                        pl.T[1] = TL;
-                        pl.V[1] = LV;
-                        pl.M[1] = LM;
+                        pl.narrow = narrow;
+                        pl.log_size = log_size;
+                        pl.eq_off = eq_off;
+                        pl.snap_lb = snap_lb;
+                        pl.need = need;
                     }
-                    const uint32_t sbase = 13 + bitmap_size(TS.LT);
-                    const DacLayout SV = dac_layout(sbase, TS.N0, 0, 0, 0);
-                    const DacLayout SM = dac_layout(SV.end, TS.M0, 0, 0, 0);
-                    pl.T[0] = TS;
-                    pl.V[0] = SV;
-                    pl.M[0] = SM;
-                    pl.narrow = narrow;
-                    pl.log_size = log_size;
-                    pl.eq_off = eq_off;
-                    pl.snap_lb = SM.end;
-                    if (need == 0) {
-                        if (!have_s || cap254 || SM.end <= log_size) need = 2;
-                        else choose(false, TL, log_size, narrow);
-                    }
-                    pl.need = need;
                 } else if (stage == 2) {  // exact classes of the log are in sh.tot[10..15]
                     pl.V[1] = dac_layout(pl.eq_off + bitmap_size(pl.T[1].LT - pl.T[1].M0), pl.T[1].N0, sh.tot[10], sh.tot[11], sh.tot[12]);
                     pl.M[1] = dac_layout(pl.V[1].end, pl.T[1].M0, sh.tot[13], sh.tot[14], sh.tot[15]);

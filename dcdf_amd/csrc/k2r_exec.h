@@ -126,6 +126,8 @@ struct GpuExec {
         lds_barrier();
     }
     static constexpr int planner() { return 0; }
+    // the value `v` of lane `lane` (a compile-time-foldable constant) of this wave, in every lane
+    __device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
     template <int NF>
     __device__ __forceinline__ void scan_finish(uint32_t (&tot)[NF]) {
         constexpr int NW = NT < 64 ? 1 : NT / 64;
@@ -224,6 +226,7 @@ struct SimExec {
         scan<NF, true>();
     }
     static constexpr int planner() { return 0; }
+    uint32_t lane_value(uint32_t v, int) const { return v; }  // (never reached: the sequential context plans on one thread)
     template <int NF>
     void scan_finish(uint32_t (&t)[NF]) {
         for (int f = 0; f < NF; f++) t[f] = sh.tot[f];
