@@ -54,13 +54,15 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; DCDF_BENCH_BACKEND=gloo lets several ranks share a card (rehearsal of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("DCDF_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from dcdf_amd import _lib as L
     from dcdf_amd.encoder import Encoder, synth_fill
@@ -134,7 +136,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
