@@ -334,7 +334,12 @@ struct PinRing {
     bool init() {
         if (ok) return true;
         for (int i = 0; i < 2; i++) {
-            if (hipHostMalloc(&buf[i], kPinBytes, hipHostMallocDefault) != hipSuccess) return false;
+            // page-locked if the system allows it; otherwise ordinary memory (the copies then stage inside the runtime)
+            if (hipHostMalloc(&buf[i], kPinBytes, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                buf[i] = std::malloc(kPinBytes);
+                if (!buf[i]) return false;
+            }
             if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
         }
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
