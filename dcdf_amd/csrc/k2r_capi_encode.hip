@@ -297,6 +297,33 @@ extern "C" int dcdf_encoder_fetch(dcdf_encoder* e, size_t i, uint8_t* dst, size_
     return DCDF_OK;
 }
 
+namespace k2r {
+hipError_t launch_object_sha256(const TileArgs* tiles, const TileResult* results, uint32_t n, uint8_t* digests, hipStream_t stream);
+}
+
+extern "C" int dcdf_encoder_object_sha256(dcdf_encoder* e, uint8_t* digests, float* kernel_ms) {
+    if (!e || !digests) return DCDF_ERR_BAD_ARG;
+    const size_t n = e->desc.size();
+    // the statuses the kernel may trust: tiles rejected on the host never reached the device
+    std::vector<TileResult> res(e->results);
+    for (size_t i = 0; i < n; i++)
+        if (e->pre_status[i] != DCDF_OK) {
+            res[i].status = ST_BAD_ARG;
+            res[i].len = 0;
+        }
+    DevBuf d_res, d_dig;
+    K2R_HIP(d_res.alloc(n * sizeof(TileResult)));
+    K2R_HIP(d_dig.alloc(n * 32));
+    K2R_HIP(hipMemcpy(d_res.p, res.data(), n * sizeof(TileResult), hipMemcpyHostToDevice));
+    K2R_HIP(hipEventRecord(e->ev0, e->stream));
+    K2R_HIP(launch_object_sha256(e->d_args.as<TileArgs>(), d_res.as<TileResult>(), (uint32_t)n, d_dig.as<uint8_t>(), e->stream));
+    K2R_HIP(hipEventRecord(e->ev1, e->stream));
+    K2R_HIP(hipStreamSynchronize(e->stream));
+    if (kernel_ms) K2R_HIP(hipEventElapsedTime(kernel_ms, e->ev0, e->ev1));
+    K2R_HIP(hipMemcpy(digests, d_dig.p, n * 32, hipMemcpyDeviceToHost));
+    return DCDF_OK;
+}
+
 extern "C" uint64_t dcdf_encoder_total_bytes(dcdf_encoder* e) {
     uint64_t s = 0;
     if (!e) return 0;

@@ -44,6 +44,20 @@ class Encoder:
         L.check(L.lib().dcdf_encoder_fetch(self._h, C.c_size_t(i), C.c_void_p(buf.ctypes.data), C.c_size_t(ln)))
         return buf.tobytes()
 
+    def object_sha256(self):
+        """SHA-256 of the stored object of every tile (the reference's 8-byte object header + chunk bytes), hashed on
+        the device; returns (digests[n, 32] uint8, kernel_ms)."""
+        out = np.zeros((self.n, 32), dtype=np.uint8)
+        ms = C.c_float()
+        L.check(L.lib().dcdf_encoder_object_sha256(self._h, C.c_void_p(out.ctypes.data), C.byref(ms)), "object_sha256")
+        return out, ms.value
+
+    def object_cids(self):
+        """Binary CIDs of the stored objects as the reference's MemoryMapper names them (testing.rs:172-183):
+        CIDv1, codec 0x12, multihash sha2-256 -> 36 bytes each; None for failed tiles."""
+        dig, _ = self.object_sha256()
+        return [None if self.result(i)[0] != 0 else bytes([0x01, 0x12, 0x12, 0x20]) + dig[i].tobytes() for i in range(self.n)]
+
     def total_bytes(self):
         return int(L.lib().dcdf_encoder_total_bytes(self._h))
 

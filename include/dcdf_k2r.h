@@ -98,6 +98,12 @@ int dcdf_encoder_result(dcdf_encoder* enc, size_t i, int32_t* status, uint64_t* 
 int dcdf_encoder_fetch(dcdf_encoder* enc, size_t i, uint8_t* dst, size_t cap);
 /* Sum of len over tiles with status 0 (for the algorithmic-bytes figure). */
 uint64_t dcdf_encoder_total_bytes(dcdf_encoder* enc);
+/* Content addressing of the stored chunk objects, computed where the encoded bytes lie (HBM): digests[32*i ..] =
+ * SHA-256 of the object the reference would store for tile i -- u16 0xDCE0, u32 1, NODE_MMSTRUCT3 (2),
+ * NODE_SUBCHUNK (4), big-endian, then the Chunk::write_to bytes (resolver.rs:17-18,126-138; mmstruct.rs:215-218) --
+ * i.e. the digest inside its CID: CIDv1, codec 0x12, multihash sha2-256 (testing.rs:172-183).  Zeros for tiles that
+ * failed.  `digests` is host memory; call after dcdf_encoder_run. */
+int dcdf_encoder_object_sha256(dcdf_encoder* enc, uint8_t* digests, float* kernel_ms);
 void dcdf_encoder_destroy(dcdf_encoder* enc);
 
 /* ---- query --------------------------------------------------------------------------------- */

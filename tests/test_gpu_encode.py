@@ -211,3 +211,46 @@ def test_row_loader_selection_aligned_and_not(dc, dtype):
     odd = np.ascontiguousarray(big[:, :64, :67])[:, :, :64]  # row stride 67 elements
     transposed = np.ascontiguousarray(big[:, :64, :64].transpose(0, 2, 1)).transpose(0, 2, 1)  # column stride != 1
     assert_same(dc, [aligned, shifted, odd, transposed], fractional_bits=fb)
+
+
+_SHA_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+import torch  # before the library: one HIP runtime per process, torch's (as in bench.py)
+sys.path.insert(0, %r)
+from dcdf_amd import _lib as L, synth
+from dcdf_amd.encoder import Encoder
+rng = np.random.default_rng(9)
+arrays = [rng.integers(-50, 50, size=(t, s, s)).astype(np.int32) for t, s in ((1, 8), (2, 8), (3, 16), (5, 32), (7, 64), (4, 128))]
+arrays += [np.zeros((1, 8, 8), dtype=np.int32), synth.cells(0xDCDF0005, 0, 6, 0, 256, 0, 256, np.int32)]
+bad = np.zeros((2, 8, 8), dtype=np.int32)
+bad[1, 1, 1] = 2 ** 30  # outside the fast path: fails, digest stays zero
+arrays.append(bad)
+dev = [torch.from_numpy(a).cuda() for a in arrays]
+enc = Encoder([(d.data_ptr(), L.DCDF_I32, tuple(s // 4 for s in a.strides), a.shape) for d, a in zip(dev, arrays)], k=2)
+enc.run()
+dig, _ = enc.object_sha256()
+cids = enc.object_cids()
+hdr = bytes([0xDC, 0xE0, 0, 0, 0, 1, 2, 4])
+lens = set()
+for i in range(len(arrays) - 1):
+    data = enc.fetch(i)
+    lens.add(len(data) %% 64)
+    want = hashlib.sha256(hdr + data).digest()
+    assert dig[i].tobytes() == want, i
+    assert cids[i] == bytes([1, 0x12, 0x12, 0x20]) + want
+assert not dig[-1].any() and cids[-1] is None
+assert len(lens) > 3  # different tail lengths exercised
+print("sha256 ok")
+"""
+
+
+def test_object_sha256_on_device(dc):
+    """Content addressing (resolver.rs:126-138 framing, testing.rs:172-183 CID): device SHA-256 of header + chunk bytes
+    against hashlib, for chunk lengths around the block boundaries and for a failed tile.  Runs in a child process:
+    the device-resident session needs torch for device memory, and torch must initialise HIP before the library does."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SHA_SCRIPT % root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sha256 ok" in r.stdout, r.stdout + r.stderr
