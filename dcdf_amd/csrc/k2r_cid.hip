@@ -63,15 +63,19 @@ __global__ void __launch_bounds__(64) k_object_sha256(const TileArgs* __restrict
     const uint8_t* data = tiles[t].out;
     const uint64_t total = len + 8;                       // message bytes
     const uint64_t nblk = (total + 1 + 8 + 63) / 64;      // + 0x80 + 64-bit length
-    const bool aligned = ((uintptr_t)data & 3) == 0;
+    const bool aligned = ((uintptr_t)data & 7) == 0;
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     for (uint64_t b = 0; b < nblk; b++) {
         uint32_t w[16];
         const uint64_t o = 64 * b;
         if (aligned && b > 0 && o + 64 <= total) {  // a full block of chunk bytes: aligned big-endian words
-            const uint32_t* p = (const uint32_t*)(data + (o - 8));
+            const uint2* p = (const uint2*)(data + (o - 8));  // 8-byte aligned: the header shifts the stream by 8
 #pragma unroll
-            for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(p[j]);
+            for (int j = 0; j < 8; j++) {
+                const uint2 v = p[j];
+                w[2 * j] = __builtin_bswap32(v.x);
+                w[2 * j + 1] = __builtin_bswap32(v.y);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
