@@ -326,8 +326,12 @@ K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int
     const uint32_t* p = scmp + ((size_t)j * C::NT + (size_t)tid) * 8;
     uint32_t w[8];
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 a = *(__attribute__((address_space(1))) const uint4*)p;
-    const uint4 b = *(__attribute__((address_space(1))) const uint4*)(p + 4);
+    // wave-uniform base (SGPR pair) + 32-bit byte offset per thread: no 64-bit address arithmetic on the VALU
+    typedef __attribute__((address_space(1))) const char* gptr;
+    const uint32_t ob = ((uint32_t)j * (uint32_t)C::NT + (uint32_t)tid) * 32u;
+    const uint4 a = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob);
+    const uint4 b = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob + 16);
+    (void)p;
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
     w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 #else
