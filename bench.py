@@ -3,18 +3,36 @@
 
 A "step" is one pass of the hot path (dcdf_encoder_run: the fused HIP encoder over every chunk of the batch,
 heuristic + DAC/bitmap packing + serialization into HBM) over one batch of synthetic chunks that is already
-resident in HBM.  Workload at N=1 = BASELINE configs[1]: 1024 independent [32,256,256] chunks (seed
-0xDCDF0002 + c).  With N ranks every rank owns its own 1024 chunks (independent units, no data-path
-collective; torch.distributed/RCCL is used only for the barrier and the max-over-ranks of the time).
+resident in HBM.
 
-Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
+Workloads
+  config2 (default, the configuration BASELINE.json's metric and target are quoted on: configs[2]/[3]):
+      ONE 4096x4096x365 raster (seed 0xDCDF0003) tiled into 16x16 tiles of 256^2 and 12 time segments of <= 32
+      instants = 3072 chunks.  With N ranks the SAME raster is sharded by chunk (dcdf_amd/shard.py, balanced by
+      cell count) -> "scaling": "strong".  No data-path collective: torch.distributed (RCCL) is used only for the
+      barrier and the max-over-ranks of the time; after the timed region every rank's encoded buffers and
+      per-instant (min,max) pairs are gathered on the host side (reported under "gather", never part of `value`).
+  config1 (--workload config1, BASELINE configs[1]): 1024 independent [32,256,256] chunks per GPU, seed
+      0xDCDF0002 + c; every rank owns its own 1024 chunks -> "scaling": "weak".
+
+Launch: `python bench.py --gpus N`.  When N > 1 and no launcher set WORLD_SIZE, this process starts N ranks itself
+(one child process per GPU, before anything here touches the GPU) and relays rank 0's line.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are the launcher's.
+
+Prints ONE JSON line on rank 0 (see the driver contract), with extra objects:
   roofline     : algorithmic bytes (input cells * sizeof + encoded bytes) / HIP-event time of the encode kernel
+                 (events recorded on the stream the kernel is launched on, inside dcdf_encoder_run)
   cpu_baseline : the CPU oracle (C++ restatement of the reference, 1 thread like the reference) on a bounded
-                 sample of the same chunks, timed on this host
+                 sample of the same chunks, timed on this host (N = 1 only)
+  gather       : the final host-side gather of {offsets, bytes, minmax} and the SHA-256 of the concatenation of all
+                 chunks in chunk order (equal for every N)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,86 +43,135 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=1024, help="chunks per GPU (configs[1]: 1024)")
-    ap.add_argument("--instants", type=int, default=32)
-    ap.add_argument("--side", type=int, default=256)
+    ap.add_argument("--workload", choices=["config1", "config2"], default="config2")
+    ap.add_argument("--chunks", type=int, default=1024, help="config1: chunks per GPU")
+    ap.add_argument("--instants", type=int, default=32, help="config1: instants per chunk")
+    ap.add_argument("--side", type=int, default=256, help="config1: tile side")
+    ap.add_argument("--days", type=int, default=365, help="config2: instants of the raster (365)")
+    ap.add_argument("--extent", type=int, default=4096, help="config2: rows = cols of the raster (4096)")
     ap.add_argument("--dtype", choices=["i32", "i64", "f32", "f64"], default="i32",
-                    help="i32 (default): stored fixed-point integers; f32: floats converted on the fly (to_fixed, --fbits)")
-    ap.add_argument("--fbits", type=int, default=3, help="fractional bits of the f32 workload")
+                    help="i32 (default): stored fixed-point integers; f32/f64: floats converted on the fly (to_fixed, --fbits)")
+    ap.add_argument("--fbits", type=int, default=3, help="fractional bits of the float workloads")
     ap.add_argument("--cpu-sample", type=int, default=24, help="chunks timed on the CPU oracle (0 = skip)")
     ap.add_argument("--verify", type=int, default=4, help="chunks compared byte-for-byte with the oracle (untimed)")
-    ap.add_argument("--pad-elems", type=int, default=0, help="extra elements between consecutive chunks in HBM")
-    ap.add_argument("--workload", choices=["config1", "config2"], default="config1",
-                    help="config1 (default, the configuration the metric is quoted on): --chunks independent chunks per GPU; "
-                         "config2: the 4096x4096x365 raster (seed 0xDCDF0003) tiled into 16x16x12 chunks of <= 32 instants, "
-                         "sharded over the ranks by chunk")
-    args = ap.parse_args()
+    ap.add_argument("--no-gather", action="store_true", help="skip the host-side gather + SHA-256 (profiling runs)")
+    ap.add_argument("--pad-elems", type=int, default=0, help="config1: extra elements between consecutive chunks in HBM")
+    return ap.parse_args(argv)
 
-    import numpy as np
-    import torch
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start N fresh rank processes (this process has not touched the GPU and never will)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def source_sha():
+    """Identifies the kernel sources a committed PMC profile belongs to (roofline.traffic is only quoted for them)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dcdf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+        print("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+
     # one rank per GPU; DCDF_BENCH_BACKEND=gloo lets several ranks share a card (rehearsal of the N > 1 path on a 1-GPU box)
     backend = os.environ.get("DCDF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank)
     dist = None
+    host_group = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        host_group = dist.group.WORLD if backend == "gloo" else dist.new_group(backend="gloo")  # the host-side gather
 
     from dcdf_amd import _lib as L
     from dcdf_amd.encoder import Encoder, synth_fill
+    from dcdf_amd.shard import my_chunks, partition
 
     name = L.lib().dcdf_device_name()
     if not name:
         raise RuntimeError("libdcdf_k2r.so sees no GPU; the MI355X path has no CPU fallback")
 
-    n, T, S = args.chunks, args.instants, args.side
     tdt = {"i32": torch.int32, "i64": torch.int64, "f32": torch.int32, "f64": torch.int32}[args.dtype]
     code = {"i32": L.DCDF_I32, "i64": L.DCDF_I64, "f32": L.DCDF_I32, "f64": L.DCDF_I32}[args.dtype]
     esz = 8 if args.dtype in ("i64", "f64") else 4
     fb = 0
     if args.workload == "config1":
+        n, T, S = args.chunks, args.instants, args.side
         per = T * S * S + args.pad_elems
         flat = torch.empty((n * per,), dtype=tdt, device="cuda")
         data = [flat[c * per:c * per + T * S * S].view(T, S, S) for c in range(n)]
         base_seed = 0xDCDF0002 + rank * n
         for c in range(n):
             synth_fill(data[c].data_ptr(), code, base_seed + c, 0, T, 0, S, 0, S)
+        ids = list(range(rank * n, rank * n + n))  # global chunk ids (for the gather order)
+        n_global = n * world
+        scaling = "weak"
         workload = "configs[1]: %d independent [%d,%d,%d] %s chunks per GPU, seed 0xDCDF0002+c" % (n, T, S, S, args.dtype)
     else:
-        # BASELINE configs[2]/[3]: one 4096x4096x365 raster; chunk (seg, i, j) = instants [32 seg, min(365, 32 seg + 32)) of
-        # rows [256 i, 256 i + 256), cols [256 j, 256 j + 256); the chunks are dealt to the ranks balanced by cell count (dcdf_amd/shard.py)
-        from dcdf_amd.shard import my_chunks, partition
+        # BASELINE configs[2]/[3]: chunk (seg, i, j) = instants [32 seg, min(days, 32 seg + 32)) of rows [256 i, 256 i + 256),
+        # cols [256 j, 256 j + 256), as Variable::append (dataset.rs:838) x Superchunk::build (superchunk.rs:127-181) cut it;
+        # dealt to the ranks balanced by cell count
         S, T = 256, 32
-        grid = [(seg, i, j) for seg in range(12) for i in range(16) for j in range(16)]
-        owner = partition([(min(365, 32 * seg + 32) - 32 * seg) * S * S for seg, _, _ in grid], world)
-        mine = [grid[g] for g in my_chunks(owner, rank)]
+        nseg, nt = (args.days + T - 1) // T, args.extent // S
+        grid = [(seg, i, j) for seg in range(nseg) for i in range(nt) for j in range(nt)]
+        seglen = lambda seg: min(args.days, T * seg + T) - T * seg
+        owner = partition([seglen(seg) * S * S for seg, _, _ in grid], world)
+        ids = my_chunks(owner, rank)
+        mine = [grid[g] for g in ids]
         n = len(mine)
-        sizes = [(min(365, 32 * seg + 32) - 32 * seg) * S * S for seg, _, _ in mine]
+        n_global = len(grid)
+        sizes = [seglen(seg) * S * S for seg, _, _ in mine]
         offs = [0]
         for z in sizes:
             offs.append(offs[-1] + z)
         flat = torch.empty((offs[-1],), dtype=tdt, device="cuda")
         data = []
         for (seg, i, j), o, z in zip(mine, offs, sizes):
-            t0, t1 = 32 * seg, min(365, 32 * seg + 32)
+            t0, t1 = T * seg, T * seg + seglen(seg)
             v = flat[o:o + z].view(t1 - t0, S, S)
             synth_fill(v.data_ptr(), code, 0xDCDF0003, t0, t1, S * i, S * i + S, S * j, S * j + S)
             data.append(v)
-        workload = "configs[2]: 4096x4096x365 %s raster, seed 0xDCDF0003, %d of 3072 [<=32,256,256] chunks on this GPU" % (args.dtype, n)
+        scaling = "strong"
+        workload = ("configs[2]: %dx%dx%d %s raster, seed 0xDCDF0003, tiled into %d [<=32,256,256] chunks; %d of them on "
+                    "this GPU" % (args.extent, args.extent, args.days, args.dtype, n_global, n))
     torch.cuda.synchronize()
     if args.dtype in ("f32", "f64"):  # the same integers as exact multiples of 2^-fbits in floating point (|v| < 2^24)
         fb = args.fbits
@@ -116,7 +183,7 @@ def main():
 
     descs = [(d.data_ptr(), code, (S * S, S, 1), tuple(d.shape), fb, 0) for d in data]
     enc = Encoder(descs, k=2)
-    cells_per_step = sum(d.numel() for d in data)
+    cells_local = sum(d.numel() for d in data)
 
     def barrier():
         torch.cuda.synchronize()
@@ -135,14 +202,69 @@ def main():
     t1 = time.perf_counter()
     barrier()
     elapsed = t1 - t0
+    cells_total = cells_local
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+        dev = "cpu" if backend == "gloo" else "cuda"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        cc = torch.tensor([cells_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        cells_total = int(cc.item())
 
     bad = sum(1 for i in range(n) if enc.result(i)[0] != 0)
     out_bytes = enc.total_bytes()
     snaps = sum(enc.result(i)[2] for i in range(n))
+
+    # ---- the final host-side gather of {offsets, bytes, minmax} (untimed w.r.t. `value`; reported on its own) --------
+    gather = None
+    if not args.no_gather:
+        g0 = time.perf_counter()
+        buf, goffs, glens, mm = enc.gather()  # device pack + one D2H copy per rank
+        g1 = time.perf_counter()
+        if dist is not None:
+            meta = [None] * world if rank == 0 else None
+            dist.gather_object((ids, glens.tolist(), int(mm.shape[0])), meta, dst=0, group=host_group)
+            if rank == 0:
+                parts = {0: (buf, goffs, glens)}
+                total_b, total_mm = int(glens.sum()), int(mm.shape[0])
+                for r in range(1, world):
+                    rl = np.array(meta[r][1], dtype=np.uint64)
+                    ro = np.zeros(len(rl), dtype=np.uint64)
+                    if len(rl) > 1:
+                        ro[1:] = np.cumsum((rl[:-1] + np.uint64(15)) & ~np.uint64(15))
+                    nb = int(((rl + np.uint64(15)) & ~np.uint64(15)).sum())
+                    rb = torch.empty(max(1, nb), dtype=torch.uint8)
+                    dist.recv(rb, src=r, group=host_group)
+                    rm = torch.empty((max(1, meta[r][2]), 2), dtype=torch.int64)
+                    dist.recv(rm, src=r, group=host_group)
+                    parts[r] = (rb.numpy(), ro, rl)
+                    total_b += int(rl.sum())
+                    total_mm += meta[r][2]
+                g2 = time.perf_counter()
+                where = {}
+                for r in range(world):
+                    for q, cid in enumerate(meta[r][0]):
+                        where[cid] = (r, q)
+                h = hashlib.sha256()
+                for cid in range(n_global):
+                    r, q = where[cid]
+                    b, o, l = parts[r]
+                    h.update(memoryview(b[int(o[q]):int(o[q]) + int(l[q])]))
+                sha, nchunks = h.hexdigest(), len(where)
+            else:
+                dist.send(torch.from_numpy(buf), dst=0, group=host_group)
+                dist.send(torch.from_numpy(mm if mm.size else np.zeros((1, 2), dtype=np.int64)), dst=0, group=host_group)
+        else:
+            g2 = g1
+            h = hashlib.sha256()
+            for q in range(n):
+                h.update(memoryview(buf[int(goffs[q]):int(goffs[q]) + int(glens[q])]))
+            sha, nchunks, total_b, total_mm = h.hexdigest(), n, int(glens.sum()), int(mm.shape[0])
+        if rank == 0:
+            gather = {"device_pack_and_d2h_s": g1 - g0, "rank_exchange_s": g2 - g1, "chunks": nchunks, "bytes": total_b,
+                      "minmax_pairs": total_mm, "sha256_of_concatenation_in_chunk_order": sha,
+                      "note": "host-side, after the timed region; equal sha256 for every --gpus N of one workload"}
 
     # ---- untimed parity spot check against the oracle (rank 0) -------------------------------------
     verified = 0
@@ -154,13 +276,14 @@ def main():
             assert enc.fetch(c) == O.chunk_build(host, fractional_bits=fb), "chunk %d: encoded bytes differ from the oracle" % c
             verified += 1
         if world == 1 and args.cpu_sample > 0:
-            m = min(args.cpu_sample, n)
-            m = min(m, sum(1 for d in data if d.shape == data[0].shape))
-            sample = torch.stack([d for d in data if d.shape == data[0].shape][:m]).cpu().numpy()
+            full = [d for d in data if d.shape[0] == T]
+            m = min(args.cpu_sample, len(full))
+            sample = torch.stack(full[:m]).cpu().numpy()
             sec, tb, _ = O.bench_build(sample)
             cpu = {"value": sample.size / sec, "unit": "cells/s", "cores": 1, "kind": "port",
-                   "sample": "first %d of the %d [%d,%d,%d] %s chunks (%.1f s); C++ restatement of the Rust "
-                             "reference, serial like superchunk.rs:166-188" % (m, n, T, S, S, args.dtype, sec)}
+                   "sample": "first %d of the %d [%d,%d,%d] %s chunks of this workload (%.1f s); C++ restatement of the Rust "
+                             "reference (no Rust toolchain), built -O3 without -march=native, serial like "
+                             "superchunk.rs:166-188" % (m, n, T, S, S, args.dtype, sec)}
             # the same port with one chunk per task on every host core (the reference itself is serial)
             from concurrent.futures import ThreadPoolExecutor
             nthr = max(1, min(16, len(os.sched_getaffinity(0))))  # a one-GPU box's CPU share is 16 cores
@@ -174,40 +297,51 @@ def main():
 
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
-        alg_bytes = cells_per_step * esz + out_bytes  # every input cell read once, every output byte written once
+        alg_bytes = cells_local * esz + out_bytes  # every input cell read once, every output byte written once
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the committed PMC passes -- only valid for the workload they were taken on
+        # HBM bytes per launch come from separate rocprofv3 PMC passes (tools/collect_profiles.sh); they are quoted only
+        # when that profile was taken on this workload with these kernel sources
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        default_workload = (args.workload, n, T, S, args.dtype, args.pad_elems) == ("config1", 1024, 32, 256, "i32", 0)
-        if default_workload and os.path.exists(tf):
+        key = "%s/%s/n%d/w%d" % (args.workload, args.dtype, n, world)
+        if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                rec = json.load(open(tf))
+                if rec.get("workload_key") == key and rec.get("source_sha") == source_sha():
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_src = rec.get("tag")
             except Exception:
                 traffic = None
         line = {
             "metric": "raster cells/s encoded (Snapshot+Log build)",
-            "value": cells_per_step * world * args.steps / elapsed,
+            "value": cells_total * args.steps / elapsed,
             "unit": "cells/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": {"i32": "int32", "i64": "int64", "f32": "f32->fixed(int32 arithmetic)", "f64": "f64->fixed(int32 arithmetic)"}[args.dtype],
             "data": "synthetic",
-            "config": {"workload": workload,
-                       "chunks_per_gpu": n, "k": 2, "device": name.decode(), "failed_tiles": bad,
-                       "encoded_bytes_per_gpu": out_bytes, "snapshots": snaps, "bytes_verified_vs_oracle": verified},
+            "config": {"workload": workload, "workload_key": key,
+                       "chunks_total": n_global, "chunks_on_rank0": n, "cells_total": cells_total, "k": 2,
+                       "device": name.decode(), "failed_tiles_rank0": bad,
+                       "encoded_bytes_rank0": out_bytes, "snapshots_rank0": snaps, "bytes_verified_vs_oracle": verified,
+                       "parallelism": "chunks sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_profile": traffic_src,
                          "kernel": "k2r::k_encode<%d,false,%d>" % (S.bit_length() - 1, {"i32": 1, "f32": 2, "i64": 3, "f64": 4}[args.dtype]),
-                         "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes},
+                         "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes, "scope": "rank 0's GPU, HIP events around the encode kernel",
+                         "source_sha": source_sha()},
             "cpu_baseline": cpu,
+            "gather": gather,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -324,6 +324,66 @@ extern "C" int dcdf_encoder_object_sha256(dcdf_encoder* e, uint8_t* digests, flo
     return DCDF_OK;
 }
 
+// ---- host-side gather of the encoded buffers ("{offsets[], bytes[]} per GPU plus the per-(chunk,instant)
+// (min,max) pairs") ------------------------------------------------------------------------------------
+// The tiles' slots are packed on the device (16-byte aligned starts, 16-byte vector copies) and come back in ONE copy.
+namespace k2r {
+struct PackItem {
+    const uint8_t* src;
+    uint64_t len;      // bytes
+    uint64_t dst_off;  // multiple of 16
+};
+__global__ void __launch_bounds__(256) k_pack(const PackItem* __restrict__ items, uint32_t n, uint8_t* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const PackItem it = items[i];
+        const uint4* s = (const uint4*)it.src;  // slots are 256-byte aligned and at least len rounded up to 256 long
+        uint4* d = (uint4*)(dst + it.dst_off);
+        const uint64_t nv = (it.len + 15) / 16;
+        for (uint64_t v = threadIdx.x; v < nv; v += blockDim.x) d[v] = s[v];
+    }
+}
+}  // namespace k2r
+
+extern "C" int dcdf_encoder_gather_size(dcdf_encoder* e, uint64_t* packed_bytes, uint64_t* minmax_words) {
+    if (!e || !packed_bytes) return DCDF_ERR_BAD_ARG;
+    uint64_t tot = 0;
+    for (size_t i = 0; i < e->desc.size(); i++)
+        if (e->pre_status[i] == DCDF_OK && e->results[i].status == ST_OK) tot += (e->results[i].len + 15) & ~15ull;
+    *packed_bytes = tot;
+    if (minmax_words) *minmax_words = e->minmax_total;
+    return DCDF_OK;
+}
+
+extern "C" int dcdf_encoder_gather(dcdf_encoder* e, uint8_t* dst, size_t cap, uint64_t* offsets, uint64_t* lens, int64_t* minmax) {
+    if (!e || !dst || !offsets || !lens) return DCDF_ERR_BAD_ARG;
+    const size_t n = e->desc.size();
+    std::vector<PackItem> items;
+    uint64_t tot = 0;
+    for (size_t i = 0; i < n; i++) {
+        const bool ok = e->pre_status[i] == DCDF_OK && e->results[i].status == ST_OK;
+        offsets[i] = tot;
+        lens[i] = ok ? e->results[i].len : 0;
+        if (!ok || lens[i] == 0) continue;
+        items.push_back(PackItem{e->args[i].out, lens[i], tot});
+        tot += (lens[i] + 15) & ~15ull;
+    }
+    if (tot > cap) return DCDF_ERR_CAPACITY;
+    if (!items.empty()) {
+        DevBuf d_items, d_packed;
+        K2R_HIP(d_items.alloc(items.size() * sizeof(PackItem)));
+        K2R_HIP(d_packed.alloc(tot));
+        K2R_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice, e->stream));
+        const uint32_t grid = (uint32_t)std::min<size_t>(items.size(), 8192);
+        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, e->stream, d_items.as<PackItem>(), (uint32_t)items.size(),
+                           d_packed.as<uint8_t>());
+        K2R_HIP(hipGetLastError());
+        K2R_HIP(hipMemcpyAsync(dst, d_packed.p, tot, hipMemcpyDeviceToHost, e->stream));
+        K2R_HIP(hipStreamSynchronize(e->stream));
+    }
+    if (minmax && e->minmax_total) K2R_HIP(hipMemcpy(minmax, e->d_minmax.p, e->minmax_total * 8, hipMemcpyDeviceToHost));
+    return DCDF_OK;
+}
+
 extern "C" uint64_t dcdf_encoder_total_bytes(dcdf_encoder* e) {
     uint64_t s = 0;
     if (!e) return 0;
@@ -618,6 +678,8 @@ extern "C" const char* dcdf_strerror(int code) {
         case DCDF_ERR_NOMEM: return "out of memory";
         case DCDF_ERR_CAPACITY: return "result buffer too small";
         case DCDF_ERR_INTERNAL: return "internal consistency guard tripped in a kernel (bug; see stderr)";
+        case DCDF_ERR_HIP: return "HIP runtime failure (see dcdf_last_hip_error)";
+        case DCDF_ERR_HIP_INVALID: return "HIP rejected an argument (bad device pointer or value)";
     }
     return "unknown error";
 }
@@ -625,4 +687,5 @@ extern "C" const char* dcdf_device_name(void) {
     Runtime& rt = Runtime::get();
     return rt.ok ? rt.name.c_str() : nullptr;
 }
-extern "C" int dcdf_abi_version(void) { return 1; }
+extern "C" int dcdf_abi_version(void) { return 2; }
+extern "C" int dcdf_last_hip_error(void) { return k2r::last_hip_error(); }

@@ -24,6 +24,18 @@ struct dcdf_chunk {
 
 namespace k2r {
 
+struct EventPair {  // destroyed on every exit path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create() {
+        hipError_t r = hipEventCreate(&e0);
+        return r != hipSuccess ? r : hipEventCreate(&e1);
+    }
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
 struct ChunkRef {  // device-visible handle of an opened chunk
     const uint8_t* bytes;
     const InstDesc* descs;
@@ -377,9 +389,9 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         K2R_HIP(d_bits.alloc(bits_words * 4));
         K2R_HIP(hipMemset(d_bits.p, 0, bits_words * 4));
         K2R_HIP(d_counts.alloc(items.size() * 4));
-        hipEvent_t e0, e1;
-        K2R_HIP(hipEventCreate(&e0));
-        K2R_HIP(hipEventCreate(&e1));
+        EventPair ev;
+        K2R_HIP(ev.create());
+        const hipEvent_t e0 = ev.e0, e1 = ev.e1;
         const uint32_t ni = (uint32_t)items.size();
         K2R_HIP(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k_search_mark, dim3((ni + 63) / 64), dim3(64), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
@@ -403,11 +415,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
             offsets[q] = acc;
             acc += counts[q];
         }
-        if (run > cap) {
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            return DCDF_ERR_CAPACITY;
-        }
+        if (run > cap) return DCDF_ERR_CAPACITY;
         if (run > 0) {
             K2R_HIP(d_offs.alloc(items.size() * 8));
             K2R_HIP(hipMemcpy(d_offs.p, item_offs.data(), items.size() * 8, hipMemcpyHostToDevice));
@@ -422,8 +430,6 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
             K2R_HIP(hipEventElapsedTime(&ms, e0, e1));
             ms_total += ms;
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     } else {
         *total_out = 0;
         for (size_t q = 0; q < nq; q++) offsets[q] = 0;
@@ -461,7 +467,10 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
     std::vector<const dcdf_chunk*> uniq;
     dedup_chunks(chunks, nq, cidx, uniq);
     std::vector<WinQuery> qs(nq);
+    // windows are decoded into a DENSE device buffer (internal offsets) and only the windows themselves are written to
+    // the caller's array: query q touches out[out_offset[q] .. + its cell count) and nothing else
     uint64_t total = 0;
+    bool dense = true;
     for (size_t q = 0; q < nq; q++) {
         if (!chunks[q]) return DCDF_ERR_BAD_ARG;
         const dcdf_cube c = norm_cube(cubes[q]);
@@ -470,8 +479,9 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
         Q = WinQuery{};
         Q.chunk = cidx[q];
         Q.start = c.start; Q.end = c.end; Q.top = c.top; Q.bottom = c.bottom; Q.left = c.left; Q.right = c.right;
-        Q.out_off = out_offset[q];
-        total = std::max<uint64_t>(total, out_offset[q] + (uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left));
+        Q.out_off = total;
+        dense = dense && out_offset[q] == total + out_offset[0];
+        total += (uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left);
     }
     if (total == 0) return DCDF_OK;
     DevBuf d_refs, d_qs, d_o;
@@ -480,21 +490,26 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
     K2R_HIP(d_qs.alloc(nq * sizeof(WinQuery)));
     K2R_HIP(hipMemcpy(d_qs.p, qs.data(), nq * sizeof(WinQuery), hipMemcpyHostToDevice));
     K2R_HIP(d_o.alloc(total * 8));
-    hipEvent_t e0, e1;
-    K2R_HIP(hipEventCreate(&e0));
-    K2R_HIP(hipEventCreate(&e1));
+    EventPair ev;
+    K2R_HIP(ev.create());
     const uint32_t grid = (uint32_t)std::min<size_t>(nq, 1u << 20);
-    K2R_HIP(hipEventRecord(e0, 0));
+    K2R_HIP(hipEventRecord(ev.e0, 0));
     hipLaunchKernelGGL(k_fill_window, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
                        (uint32_t)nq, d_o.p, (int32_t)DCDF_I64, (int64_t)0, (int64_t)0, (int64_t)0, 0);
-    K2R_HIP(hipEventRecord(e1, 0));
+    K2R_HIP(hipEventRecord(ev.e1, 0));
     K2R_HIP(hipGetLastError());
-    K2R_HIP(hipMemcpy(out, d_o.p, total * 8, hipMemcpyDeviceToHost));
+    if (dense) {  // the usual case: windows back to back in query order -> one copy straight into the caller's array
+        K2R_HIP(hipMemcpy(out + out_offset[0], d_o.p, total * 8, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<int64_t> tmp(total);
+        K2R_HIP(hipMemcpy(tmp.data(), d_o.p, total * 8, hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < nq; q++) {
+            const uint64_t cells = (uint64_t)(qs[q].end - qs[q].start) * (qs[q].bottom - qs[q].top) * (qs[q].right - qs[q].left);
+            if (cells) std::memcpy(out + out_offset[q], tmp.data() + qs[q].out_off, cells * 8);
+        }
+    }
     float ms = 0.f;
-    K2R_HIP(hipEventElapsedTime(&ms, e0, e1));
+    K2R_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     if (kernel_ms) *kernel_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return DCDF_OK;
 }
-

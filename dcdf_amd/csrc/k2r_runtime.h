@@ -52,17 +52,34 @@ inline int map_status(int32_t st) {
         case ST_UNSUPPORTED: return DCDF_ERR_UNSUPPORTED;
         case ST_BAD_ARG: return DCDF_ERR_BAD_ARG;
         case ST_INTERNAL: return DCDF_ERR_INTERNAL;
-        default: return DCDF_ERR_NO_DEVICE;
+        default: return DCDF_ERR_INTERNAL;  // unknown kernel status
     }
 }
 
+// HIP failures keep their identity: out-of-memory, no-device and launch/runtime failures map to distinct DCDF codes,
+// and the raw hipError_t of the last failure on this thread can be read back with dcdf_last_hip_error().
+inline int& last_hip_error() {
+    static thread_local int e = 0;
+    return e;
+}
+inline int map_hip_error(hipError_t e) {
+    last_hip_error() = (int)e;
+    switch (e) {
+        case hipErrorOutOfMemory: return DCDF_ERR_NOMEM;
+        case hipErrorNoDevice:
+        case hipErrorInvalidDevice:
+        case hipErrorInsufficientDriver:
+        case hipErrorNotInitialized: return DCDF_ERR_NO_DEVICE;
+        case hipErrorInvalidValue:
+        case hipErrorInvalidDevicePointer:
+        case hipErrorInvalidMemcpyDirection: return DCDF_ERR_HIP_INVALID;
+        default: return DCDF_ERR_HIP;  // launch failures, illegal address, ECC ... (see dcdf_last_hip_error)
+    }
+}
 #define K2R_HIP(call)                                  \
     do {                                               \
         hipError_t _e = (call);                        \
-        if (_e != hipSuccess) {                        \
-            if (_e == hipErrorOutOfMemory) return DCDF_ERR_NOMEM; \
-            return DCDF_ERR_NO_DEVICE;                 \
-        }                                              \
+        if (_e != hipSuccess) return k2r::map_hip_error(_e); \
     } while (0)
 
 }  // namespace k2r

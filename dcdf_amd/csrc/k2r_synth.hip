@@ -114,3 +114,27 @@ extern "C" int dcdf_calib_read(const void* tiles_device, uint32_t n_tiles, uint3
     K2R_HIP(hipDeviceSynchronize());
     return DCDF_OK;
 }
+
+// ---- device memory for callers without a HIP binding of their own (the ctypes mirror, tests, tools): plain
+// hipMalloc / hipFree / hipMemcpy behind the C ABI, so that device-resident sessions need no third-party runtime ----
+extern "C" int dcdf_device_alloc(size_t bytes, void** out) {
+    using namespace k2r;
+    if (!out) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    void* p = nullptr;
+    K2R_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    *out = p;
+    return DCDF_OK;
+}
+extern "C" int dcdf_device_free(void* p) {
+    using namespace k2r;
+    if (p) K2R_HIP(hipFree(p));
+    return DCDF_OK;
+}
+extern "C" int dcdf_device_copy(void* dst, const void* src, size_t bytes, int to_device) {
+    using namespace k2r;
+    if ((!dst || !src) && bytes) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    if (bytes) K2R_HIP(hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    return DCDF_OK;
+}

@@ -44,6 +44,20 @@ class Encoder:
         L.check(L.lib().dcdf_encoder_fetch(self._h, C.c_size_t(i), C.c_void_p(buf.ctypes.data), C.c_size_t(ln)))
         return buf.tobytes()
 
+    def gather(self):
+        """Host-side gather of this GPU's results (dcdf_encoder_gather): returns (buf uint8, offsets uint64[n],
+        lens uint64[n], minmax int64[sum instants, 2]); tile i's Chunk::write_to bytes are buf[offsets[i]:offsets[i]+lens[i]]."""
+        nb, nm = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().dcdf_encoder_gather_size(self._h, C.byref(nb), C.byref(nm)), "gather_size")
+        buf = np.empty(max(1, nb.value), dtype=np.uint8)
+        offs = np.zeros(self.n, dtype=np.uint64)
+        lens = np.zeros(self.n, dtype=np.uint64)
+        mm = np.zeros((max(1, nm.value) // 2, 2), dtype=np.int64)
+        L.check(L.lib().dcdf_encoder_gather(self._h, C.c_void_p(buf.ctypes.data), C.c_size_t(buf.size),
+                                            C.c_void_p(offs.ctypes.data), C.c_void_p(lens.ctypes.data),
+                                            C.c_void_p(mm.ctypes.data)), "gather")
+        return buf, offs, lens, mm
+
     def object_sha256(self):
         """SHA-256 of the stored object of every tile (the reference's 8-byte object header + chunk bytes), hashed on
         the device; returns (digests[n, 32] uint8, kernel_ms)."""
@@ -79,3 +93,33 @@ def synth_fill(dev_ptr, dtype_code, seed, t0, t1, r0, r1, c0, c1):
     L.check(L.lib().dcdf_synth_fill(C.c_void_p(dev_ptr), C.c_int32(dtype_code), C.c_uint64(seed), C.c_int64(t0),
                                     C.c_int64(t1), C.c_int64(r0), C.c_int64(r1), C.c_int64(c0), C.c_int64(c1),
                                     C.c_void_p(tab.ctypes.data)), "synth_fill")
+
+
+class DeviceBuffer:
+    """A plain device allocation through the C ABI (dcdf_device_alloc): lets device-resident sessions run without torch."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        L.check(L.lib().dcdf_device_alloc(C.c_size_t(self.nbytes), C.byref(p)), "device_alloc")
+        self.ptr = p.value
+
+    def read(self, offset, nbytes, dtype=np.uint8):
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        L.check(L.lib().dcdf_device_copy(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr + offset), C.c_size_t(nbytes), 0))
+        return out
+
+    def write(self, offset, array):
+        a = np.ascontiguousarray(array)
+        L.check(L.lib().dcdf_device_copy(C.c_void_p(self.ptr + offset), C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            L.lib().dcdf_device_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,139 @@
+"""A tiled, time-segmented raster of encoded chunks: the callers either side of the chunk path, reduced to routing.
+
+The reference cuts a [instants, rows, cols] variable into time segments of `chunk_size` instants
+(`Variable::append`, dataset.rs:838; queried through `Span::fill_window` / `Span::search`, span.rs:183-275) and each
+segment into `tile` x `tile` sub-arrays (`Superchunk::build`, superchunk.rs:127-181; queried through
+`Superchunk::subchunks_for`, superchunk.rs:589-633).  Every (segment, tile row, tile col) is one `Chunk`.  This module
+does that routing on the host -- vectorised over a whole batch of queries -- and sends the chunk-level sub-queries
+through the batched C-ABI entry points (dcdf_query_fill_window_batch / dcdf_query_search_batch); the decoding itself is
+on the GPU.  BASELINE configs[4] is exactly this with tile = 256, chunk_size = 32.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class EncodedRaster:
+    def __init__(self, shape, chunks, tile=256, chunk_size=32):
+        """shape = (instants, rows, cols); chunks[(seg * nti + ti) * ntj + tj] = dcdf_amd.Chunk (opened or lazy)."""
+        self.shape = tuple(int(x) for x in shape)
+        self.tile, self.chunk_size = int(tile), int(chunk_size)
+        self.nseg = -(-self.shape[0] // self.chunk_size)
+        self.nti = -(-self.shape[1] // self.tile)
+        self.ntj = -(-self.shape[2] // self.tile)
+        if len(chunks) != self.nseg * self.nti * self.ntj:
+            raise ValueError("expected %d chunks" % (self.nseg * self.nti * self.ntj))
+        self.chunks = list(chunks)
+
+    @staticmethod
+    def chunk_grid(shape, tile=256, chunk_size=32):
+        """[(t0, t1, r0, r1, c0, c1)] of every chunk, in chunk-id order (segment-major, then tile row, tile col)."""
+        T, R, Cc = shape
+        out = []
+        for t0 in range(0, T, chunk_size):
+            for r0 in range(0, R, tile):
+                for c0 in range(0, Cc, tile):
+                    out.append((t0, min(T, t0 + chunk_size), r0, min(R, r0 + tile), c0, min(Cc, c0 + tile)))
+        return out
+
+    # ---- routing: dataset-level cubes -> chunk-level sub-queries -------------------------------------------------
+    def split(self, cubes):
+        """cubes: int array [n, 6] of half-open (t0, t1, r0, r1, c0, c1), already inside the raster.  Returns
+        sub[m, 8] = (query, chunk id, local t0, t1, r0, r1, c0, c1), ordered by query, then segment, tile row, tile col
+        (span.rs:190-216 over time, superchunk.rs:589-633 over rows/cols)."""
+        q = np.asarray(cubes, dtype=np.int64)
+        n = len(q)
+        cs, tl = self.chunk_size, self.tile
+        s0, s1 = q[:, 0] // cs, (q[:, 1] - 1) // cs
+        i0, i1 = q[:, 2] // tl, (q[:, 3] - 1) // tl
+        j0, j1 = q[:, 4] // tl, (q[:, 5] - 1) // tl
+        empty = (q[:, 1] <= q[:, 0]) | (q[:, 3] <= q[:, 2]) | (q[:, 5] <= q[:, 4])
+        ns = np.where(empty, 0, s1 - s0 + 1)
+        ni = np.where(empty, 0, i1 - i0 + 1)
+        nj = np.where(empty, 0, j1 - j0 + 1)
+        cnt = ns * ni * nj
+        m = int(cnt.sum())
+        qid = np.repeat(np.arange(n), cnt)
+        first = np.repeat(np.cumsum(cnt) - cnt, cnt)
+        k = np.arange(m) - first  # ordinal of the sub-query inside its query
+        nij = (ni * nj)[qid]
+        ds, rem = k // nij, k % nij
+        di, dj = rem // nj[qid], rem % nj[qid]
+        seg, ti, tj = s0[qid] + ds, i0[qid] + di, j0[qid] + dj
+        a0, a1 = np.maximum(q[qid, 0], seg * cs), np.minimum(q[qid, 1], seg * cs + cs)
+        b0, b1 = np.maximum(q[qid, 2], ti * tl), np.minimum(q[qid, 3], ti * tl + tl)
+        d0, d1 = np.maximum(q[qid, 4], tj * tl), np.minimum(q[qid, 5], tj * tl + tl)
+        cid = (seg * self.nti + ti) * self.ntj + tj
+        return np.stack([qid, cid, a0 - seg * cs, a1 - seg * cs, b0 - ti * tl, b1 - ti * tl, d0 - tj * tl, d1 - tj * tl], axis=1)
+
+    def _origin(self, cid):
+        seg, rem = cid // (self.nti * self.ntj), cid % (self.nti * self.ntj)
+        return seg * self.chunk_size, (rem // self.ntj) * self.tile, (rem % self.ntj) * self.tile
+
+    def _handles(self, sub):
+        return (C.c_void_p * len(sub))(*[self.chunks[int(c)]._h for c in sub[:, 1]])
+
+    # ---- queries ---------------------------------------------------------------------------------------------------
+    def window_pieces(self, cubes):
+        """fill_window of every cube, as decoded pieces: returns (sub, out int64[total], woff, vol, kernel_ms); the
+        piece of sub-query k is out[woff[k]:woff[k]+vol[k]] shaped by its local cube."""
+        sub = self.split(cubes)
+        m = len(sub)
+        vol = ((sub[:, 3] - sub[:, 2]) * (sub[:, 5] - sub[:, 4]) * (sub[:, 7] - sub[:, 6])).astype(np.uint64)
+        woff = np.zeros(m, dtype=np.uint64)
+        if m > 1:
+            woff[1:] = np.cumsum(vol)[:-1]
+        total = int(vol.sum())
+        out = np.empty(max(total, 1), dtype=np.int64)
+        ms = C.c_float()
+        if m:
+            cub = np.ascontiguousarray(sub[:, 2:8].astype(np.uint32))
+            L.check(L.lib().dcdf_query_fill_window_batch(self._handles(sub), cub.ctypes.data_as(C.POINTER(L.Cube)), C.c_size_t(m),
+                                                         C.c_void_p(out.ctypes.data), C.c_void_p(woff.ctypes.data), C.byref(ms)),
+                    "fill_window_batch")
+        return sub, out[:total], woff, vol, ms.value
+
+    def fill_windows(self, cubes):
+        """[ndarray[t, r, c] int64 stored values] per cube (mmarray.rs:186 `window` over the whole raster)."""
+        q = np.asarray(cubes, dtype=np.int64)
+        sub, out, woff, vol, _ = self.window_pieces(q)
+        res = [np.zeros((max(0, c[1] - c[0]), max(0, c[3] - c[2]), max(0, c[5] - c[4])), dtype=np.int64) for c in q]
+        for k in range(len(sub)):
+            qi, cid, a0, a1, b0, b1, d0, d1 = (int(x) for x in sub[k])
+            t, r, c = self._origin(cid)
+            piece = out[int(woff[k]):int(woff[k]) + int(vol[k])].reshape(a1 - a0, b1 - b0, d1 - d0)
+            res[qi][t + a0 - q[qi, 0]:t + a1 - q[qi, 0], r + b0 - q[qi, 2]:r + b1 - q[qi, 2],
+                    c + d0 - q[qi, 4]:c + d1 - q[qi, 4]] = piece
+        return res
+
+    def search_pieces(self, cubes, lower, upper):
+        """search of every cube: returns (sub, triples uint32[hits, 3] local to their chunk, soff, counts, kernel_ms)."""
+        sub = self.split(cubes)
+        m = len(sub)
+        lo = np.ascontiguousarray(np.asarray(lower, dtype=np.int64)[sub[:, 0]])
+        hi = np.ascontiguousarray(np.asarray(upper, dtype=np.int64)[sub[:, 0]])
+        counts = np.zeros(m, dtype=np.uint64)
+        soff = np.zeros(m, dtype=np.uint64)
+        cap = int(((sub[:, 3] - sub[:, 2]) * (sub[:, 5] - sub[:, 4]) * (sub[:, 7] - sub[:, 6])).sum())
+        trip = np.empty((max(cap, 1), 3), dtype=np.uint32)
+        ms = C.c_float()
+        if m:
+            cub = np.ascontiguousarray(sub[:, 2:8].astype(np.uint32))
+            L.check(L.lib().dcdf_query_search_batch(self._handles(sub), cub.ctypes.data_as(C.POINTER(L.Cube)), C.c_void_p(lo.ctypes.data),
+                                                    C.c_void_p(hi.ctypes.data), C.c_size_t(m), C.c_void_p(trip.ctypes.data),
+                                                    C.c_size_t(cap), C.c_void_p(counts.ctypes.data), C.c_void_p(soff.ctypes.data),
+                                                    C.byref(ms)), "search_batch")
+        return sub, trip, soff, counts, ms.value
+
+    def search(self, cubes, lower, upper):
+        """[int64[hits, 3] (instant, row, col) in raster coordinates] per cube (mmarray.rs:206; span.rs:231-270 adds the
+        segment offset, superchunk.rs:516-585 the tile origin)."""
+        sub, trip, soff, counts, _ = self.search_pieces(cubes, lower, upper)
+        res = [[] for _ in range(len(cubes))]
+        for k in range(len(sub)):
+            if counts[k]:
+                org = np.array(self._origin(int(sub[k, 1])), dtype=np.int64)
+                res[int(sub[k, 0])].append(trip[int(soff[k]):int(soff[k]) + int(counts[k])].astype(np.int64) + org)
+        return [np.concatenate(r) if r else np.zeros((0, 3), dtype=np.int64) for r in res]

@@ -40,7 +40,9 @@ enum {
     DCDF_ERR_NO_DEVICE = -9,     /* no gfx950 device / HIP runtime failure                         */
     DCDF_ERR_NOMEM = -10,
     DCDF_ERR_CAPACITY = -11,     /* result buffer too small (search): *n holds the needed count    */
-    DCDF_ERR_INTERNAL = -12      /* an internal consistency guard of the kernels tripped (a bug)     */
+    DCDF_ERR_INTERNAL = -12,     /* an internal consistency guard of the kernels tripped (a bug)     */
+    DCDF_ERR_HIP = -13,          /* a HIP runtime call failed (launch failure, fault ...): dcdf_last_hip_error() */
+    DCDF_ERR_HIP_INVALID = -14   /* HIP rejected an argument (bad device pointer / value)                        */
 };
 
 /* One `Chunk::build` input: a borrowed strided 3-D view [instants, rows, cols]
@@ -98,6 +100,13 @@ int dcdf_encoder_result(dcdf_encoder* enc, size_t i, int32_t* status, uint64_t* 
 int dcdf_encoder_fetch(dcdf_encoder* enc, size_t i, uint8_t* dst, size_t cap);
 /* Sum of len over tiles with status 0 (for the algorithmic-bytes figure). */
 uint64_t dcdf_encoder_total_bytes(dcdf_encoder* enc);
+/* The final host-side gather of one GPU's encoded buffers (superchunk.rs:183-235 consumes them in tile order): tile i's
+ * bytes land at dst + offsets[i] (16-byte aligned starts, lens[i] bytes; 0 for failed tiles), packed on the device and
+ * copied back in one transfer; minmax (may be NULL) receives the per-(tile, instant) stored (min,max) pairs in tile
+ * order, 2 * instants words per tile (what Superchunk::build recomputes at superchunk.rs:144).
+ * dcdf_encoder_gather_size tells how large dst (bytes) and minmax (int64 words) must be. */
+int dcdf_encoder_gather_size(dcdf_encoder* enc, uint64_t* packed_bytes, uint64_t* minmax_words);
+int dcdf_encoder_gather(dcdf_encoder* enc, uint8_t* dst, size_t cap, uint64_t* offsets, uint64_t* lens, int64_t* minmax);
 /* Content addressing of the stored chunk objects, computed where the encoded bytes lie (HBM): digests[32*i ..] =
  * SHA-256 of the object the reference would store for tile i -- u16 0xDCE0, u32 1, NODE_MMSTRUCT3 (2),
  * NODE_SUBCHUNK (4), big-endian, then the Chunk::write_to bytes (resolver.rs:17-18,126-138; mmstruct.rs:215-218) --
@@ -160,10 +169,19 @@ int dcdf_synth_fill(void* dst_device, int32_t dtype, uint64_t seed, int64_t t0, 
  * load pattern, so rocprofv3's FETCH_SIZE can be calibrated against a known byte count (MI355X_MICROARCH.md). */
 int dcdf_calib_read(const void* tiles_device, uint32_t n_tiles, uint32_t instants);
 
+/* Device memory for callers that have no HIP binding of their own (the ctypes mirror, tests, tools): hipMalloc /
+ * hipFree / hipMemcpy (to_device != 0: host -> device, else device -> host). */
+int dcdf_device_alloc(size_t bytes, void** out);
+int dcdf_device_free(void* p);
+int dcdf_device_copy(void* dst, const void* src, size_t bytes, int to_device);
+
 const char* dcdf_strerror(int code);
 /* "gfx950 <device name>, <CUs> CUs" or NULL when no device. */
 const char* dcdf_device_name(void);
 int dcdf_abi_version(void);
+/* The raw hipError_t of the last HIP failure seen by this thread (0 = none), for DCDF_ERR_HIP / _HIP_INVALID /
+ * _NO_DEVICE / _NOMEM returns. */
+int dcdf_last_hip_error(void);
 
 #ifdef __cplusplus
 }

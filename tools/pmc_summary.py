@@ -49,4 +49,10 @@ if "fetch" in res and "write" in res:
     if line:
         res["algorithmic_bytes_per_launch"] = line["roofline"]["algorithmic_bytes"]
 json.dump(res, open(out + "/%s_pmc_summary.json" % tag, "w"), indent=1)
+if line and "hbm_bytes_per_launch" in res:
+    # what bench.py quotes as roofline.traffic -- only for this workload and these kernel sources
+    json.dump({"tag": tag, "workload_key": line["config"].get("workload_key"), "source_sha": line["roofline"].get("source_sha"),
+               "hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "fetch_bytes_x2": res["hbm_fetch_bytes_per_launch_corrected_x2"],
+               "write_bytes": res["hbm_write_bytes_per_launch"], "algorithmic_bytes_per_launch": res.get("algorithmic_bytes_per_launch")},
+              open(out + "/traffic_latest.json", "w"), indent=1)
 print(json.dumps({k: res[k] for k in res if k.startswith("hbm") or k.startswith("alg")}))
