@@ -148,10 +148,12 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
     // diagnostic knob (A/B runs): cap the LDS words the log stash may use; 1 = always take the re-reading passes
     uint32_t stash_words = 0;
     if (const char* sw = std::getenv("K2R_STASH_WORDS")) stash_words = (uint32_t)std::atoi(sw);
+    const uint32_t tile_flags = std::getenv("K2R_NO_FAST") ? 1u : 0u;  // A/B runs: general path only
     for (size_t i = 0; i < n; i++) {
         const dcdf_tile_desc& t = tiles[i];
         TileArgs a{};
         a.stash_words = stash_words;
+        a.flags = tile_flags;
         a.base = t.base;
         a.st = t.stride_t; a.sr = t.stride_r; a.sc = t.stride_c;
         a.instants = t.instants; a.rows = t.rows; a.cols = t.cols;
@@ -232,8 +234,8 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
         for (int k = 0; k < NPROF; k++) tot += acc[k];
         static const char* names[NPROF] = {"p1 load+analysis", "p2 top", "p3 own/top nodes", "reduce4", "clear+hdr",
                                            "emit C snapshot", "emit C/Q log", "T/eqB bitmaps", "Lmax dac | V0,M0 bitmaps", "Lmin dac | zero bitmaps",
-                                           "emit pass A", "emit pass B/I", "sizes+heuristic", "winner scan", "byte-1 pass A", "byte-1 pass I",
-                                           "byte-1 pass Q", "-", "-", "-"};
+                                           "emit pass A", "emit pass B/I", "sizes+heuristic", "winner scan", "byte-1 pass A", "fast: phase 1",
+                                           "fast: wait p1", "fast: top+plan", "fast: copy-out", "fast: bitmaps"};
         for (int k = 0; k < NPROF; k++)
             std::fprintf(stderr, "k2r-prof %-18s %14llu cyc %5.1f%%\n", names[k], (unsigned long long)acc[k],
                          tot ? 100.0 * (double)acc[k] / (double)tot : 0.0);

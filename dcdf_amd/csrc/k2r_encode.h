@@ -319,16 +319,27 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
     }
 }
 
+// Experimental level-order streaming log path (k2r_fastlog.h).  Bit-exact (tests/test_sim_fastlog.py, and on the card), but
+// measured SLOWER than the general path on MI355X: it trades barriers and record decoding for more
+// instructions per cell, and the kernel is bound by instruction issue, not by barriers.  Off unless built with -DK2R_FASTLOG=1.
+#ifndef K2R_FASTLOG
+#define K2R_FASTLOG 0
+#endif
 // The compact copy of a block's snapshot instant (see encode_chunk): 16 cells of sub-block j of thread tid, uint16
-// offsets from `base`, at words [(j * NT + tid) * 8, +8).
+// offsets from `base`.  General path: words [(j * NT + tid) * 8, +8) (a wave reads 2 KB contiguous per sub-block); with the
+// fast log path compiled in: [(tid * 4 + j) * 8, +8), the Morton order of the height-2 nodes that path walks.
+template <class C>
+K2R_HD uint32_t compact_slot(int tid, int j) {
+    return K2R_FASTLOG ? (uint32_t)tid * 4u + (uint32_t)j : (uint32_t)j * (uint32_t)C::NT + (uint32_t)tid;
+}
 template <class C>
 K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int32_t (&dst)[16]) {
-    const uint32_t* p = scmp + ((size_t)j * C::NT + (size_t)tid) * 8;
+    const uint32_t* p = scmp + (size_t)compact_slot<C>(tid, j) * 8;
     uint32_t w[8];
 #if defined(__HIP_DEVICE_COMPILE__)
     // wave-uniform base (SGPR pair) + 32-bit byte offset per thread: no 64-bit address arithmetic on the VALU
     typedef __attribute__((address_space(1))) const char* gptr;
-    const uint32_t ob = ((uint32_t)j * (uint32_t)C::NT + (uint32_t)tid) * 32u;
+    const uint32_t ob = compact_slot<C>(tid, j) * 32u;
     const uint4 a = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob);
     const uint4 b = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob + 16);
     (void)p;
@@ -345,7 +356,7 @@ K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int
 }
 template <class C>
 K2R_HD void store_compact(uint32_t* scmp, int tid, int j, int32_t base, const int32_t (&src)[16]) {
-    uint32_t* p = scmp + ((size_t)j * C::NT + (size_t)tid) * 8;
+    uint32_t* p = scmp + (size_t)compact_slot<C>(tid, j) * 8;
     uint32_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) w[i] = (uint32_t)(src[2 * i] - base) | ((uint32_t)(src[2 * i + 1] - base) << 16);
@@ -482,11 +493,21 @@ struct Totals {
     uint32_t offI[C::H + 2];  // Lmin index of the first internal node of height h
     uint32_t offZ[C::H + 2];  // eqB index of the first T=0 node of height h
     uint32_t LT, N0, M0;
+    K2R_HD void from_counts(const uint32_t* ni) {  // ni[1..H] = internal nodes per height
+        constexpr int H = C::H;
+#pragma unroll
+        for (int h = 1; h <= H; h++) Ni[h] = ni[h];
+        finish();
+    }
     // internal counts of heights 1..3 come from the reduced lo pack, those of heights 4..H from the bitset
     K2R_HD void from(uint64_t lo, uint64_t top) {
         constexpr int H = C::H;
 #pragma unroll
         for (int h = 1; h <= H; h++) Ni[h] = unpackI(h, lo, top);
+        finish();
+    }
+    K2R_HD void finish() {
+        constexpr int H = C::H;
         Ni[H + 1] = 0;
         uint32_t v = 0, i = 0, z = 0;
 #pragma unroll
@@ -521,17 +542,11 @@ struct InstPlan {
     uint32_t lngV[3], lngM[3];  // log: index (among second bytes) of the first one of heights 0..2
 };
 
+template <class C, int STAGE_WORDS>
+struct FastShared;
 template <class C>
-struct EncShared {
-    int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
-    uint32_t eq[C::NTOP];
-    uint32_t bmT[C::WT + 1], bmE[C::WT + 1];
-    uint32_t bmV0[C::WV + 1];
-    uint32_t bmM[2][C::WT + 1];
-    uint32_t prefM[C::WT + 2];
-    uint32_t wsum[C::NW][MAX_SCAN_FIELDS];
-    uint32_t tot[MAX_SCAN_FIELDS];
-    // One pool of LDS words with three lives per instant:
+struct EncPool {
+    // One pool of LDS words with three lives per instant (general path):
     //  (1) phase 1 .. plane-0 emission of a Log: the STASH.  While the cells of a block are in registers, phase 1
     //      records everything the emission of the log candidate will need below height 2 -- one 5-word I record per
     //      internal height-2 node (growing up from word 0) and one 3-word Q record per internal quad (growing down
@@ -543,7 +558,36 @@ struct EncShared {
     static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
     static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
     static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? 4900 : 0);  // sidelen 256: LDS filled to 160 KB
-    uint32_t pool[POOLW];
+    static constexpr int GENERAL_WORDS = 6 * C::NTOP + POOLW;   // tmin .. eq + pool: what the fast log path may alias
+    // staging words of the fast log path (k2r_fastlog.h): at sidelen 256 whatever the aliased area leaves after its tables,
+    // below that LDS is plentiful: 2 bytes per cell
+    static constexpr int FAST_FIXED = 2 * C::NW * 44 + C::NW * 4 * 14 + C::NW * 20 + 24 + 25 * C::NW + 64;
+    static constexpr int STAGE_WORDS = C::NT < 64 ? 2 : (C::H == 8 ? ((GENERAL_WORDS - FAST_FIXED) & ~1) : (1 << (2 * C::H - 1)));
+};
+
+template <class C>
+struct EncShared : EncPool<C> {
+    using EncPool<C>::POOL_L1;
+    using EncPool<C>::POOL_BMV1;
+    using EncPool<C>::POOL_PREFV;
+    using EncPool<C>::POOLW;
+    union {
+        struct {  // the general path (this file)
+            int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
+            uint32_t eq[C::NTOP];
+            uint32_t pool[EncPool<C>::POOLW];
+        };
+#if K2R_FASTLOG
+        FastShared<C, EncPool<C>::STAGE_WORDS> fast;  // the fast log path (k2r_fastlog.h); the two alternate per instant
+#endif
+    };
+    uint32_t f_top, f_flags;  // fast path: staging pool allocation pointer (8-byte units), failure flags
+    uint32_t bmT[C::WT + 1], bmE[C::WT + 1];
+    uint32_t bmV0[C::WV + 1];
+    uint32_t bmM[2][C::WT + 1];
+    uint32_t prefM[C::WT + 2];
+    uint32_t wsum[C::NW][MAX_SCAN_FIELDS];
+    uint32_t tot[MAX_SCAN_FIELDS];
     K2R_HD uint32_t* L2() { return pool; }                                  // key = blk<<2|j | (quads before) << 12
     K2R_HD uint16_t* L1() { return (uint16_t*)(pool + POOL_L1); }           // key = blk<<4|j<<2|qq
     K2R_HD uint32_t* bmV1() { return pool + POOL_BMV1; }
@@ -861,6 +905,12 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
     }
 }
 
+}  // namespace k2r
+#if K2R_FASTLOG
+#include "k2r_fastlog.h"
+#endif
+namespace k2r {
+
 // ======================================================================================================
 // The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 (1), float32 (2) or
 // int64 (3) / float64 (4) input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
@@ -919,6 +969,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             sh.err = 0;
             sh.stI = 0;
             sh.stQ = 0;
+            sh.f_top = 0;
+            sh.f_flags = 0;
             for (int i = 0; i < 6; i++) sh.fault[i] = 0;
             for (int i = 0; i < NPROF; i++) sh.prof[i] = 0;
             if (cap >= 6) {
@@ -932,8 +984,37 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     if (!EX::kSim) ex.par([&](int tid, EncRegs&) { if (tid == 0) sh.prof_last = clock64(); });
 #endif
 
+    // The fast log path (k2r_fastlog.h) is tried first for every instant that has a compact snapshot to be compared with;
+    // when it declines (the instant becomes a Snapshot, wide values, ...) the general path below encodes the instant.
+    constexpr bool kFast = K2R_FASTLOG && !PADDED && C::NT >= 64;
+    bool last_general = true;   // the general path's last phase has no closing barrier
+    uint32_t fast_fail = 0, fast_skip = 0, n_fast = 0;
     for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
         const bool have_s = inst > 0;
+#if K2R_FASTLOG
+        if constexpr (kFast) {
+            if (have_s && s_cmp && !(ta.flags & 1u) && fast_skip == 0) {
+                if (last_general) ex.barrier();
+                last_general = false;
+                uint32_t fsize = 0;
+                if (fast_log_instant<C, VEC>(ex, ta, inst, scmp, s_base, out + off, cap - off, blk_count - 1 == 254, fsize)) {
+                    n_log++;
+                    n_fast++;
+                    fast_fail = 0;
+                    off += fsize;
+                    blk_count++;
+                    continue;
+                }
+                // declined: back off when it keeps declining (data whose instants all become Snapshots, or are all wide)
+                fast_fail++;
+                if (fast_fail >= 2) fast_skip = fast_fail >= 5 ? 8u : (1u << (fast_fail - 2));
+            } else if (fast_skip) {
+                fast_skip--;
+            }
+        }
+#endif
+        (void)kFast; (void)fast_fail; (void)fast_skip; (void)last_general;
+        last_general = true;
 
         // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
         // Nothing but four per-height-2 summaries survives this phase in registers: cells are re-read on
@@ -1494,8 +1575,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             s_idx = inst;
             n_snap++;
             const int32_t rmin = ex.uni(sh.tmin[C::top_off(H)]), rmax = ex.uni(sh.tmax[C::top_off(H)]);
-            s_base = rmin;
             s_cmp = (int64_t)rmax - (int64_t)rmin <= 65535 && inst + 1 < ta.instants;
+            // the 16-bit window of the compact copy is centred on the snapshot's range: the fast log path (k2r_fastlog.h)
+            // needs the LATER instants of the block inside it too, and those drift either way
+            s_base = s_cmp ? rmin - (65535 - (rmax - rmin)) / 2 : rmin;
         } else {
             n_log++;
         }
@@ -1929,6 +2012,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             res->snapshots = n_snap;
             res->logs = n_log;
             res->stash_logs = n_stash;
+            res->fast_logs = n_fast;
             res->len = (status == ST_OK && !faulted) ? off : 0;
             for (int i = 0; i < 6; i++) res->dbg[i] = sh.fault[i];
             for (int i = 0; i < NPROF; i++) res->prof[i] = sh.prof[i];
