@@ -68,6 +68,10 @@ struct dcdf_encoder {
     std::vector<size_t> lists_off;     // per class offset (u64 words) into d_lists
     std::vector<uint32_t> grid;
     std::vector<std::unique_ptr<DevBuf>> retry_slots;  // bigger slots for tiles that overflowed
+    // tiles outside the fused kernel's contract (k != 2, sidelen < 8 or > 256): encoded by the universal kernel
+    // (k2r_generic.hip); key = k << 8 | H
+    std::vector<std::pair<uint32_t, std::vector<uint32_t>>> generic_groups;
+    std::vector<uint8_t> is_generic;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t minmax_total = 0;
@@ -79,13 +83,35 @@ struct dcdf_encoder {
     }
 };
 
-static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls) {
+// smallest H with k^H >= max(rows, cols) (snapshot.rs:118-119; the float formula is exact for every size this library accepts)
+static uint32_t depth_for(uint32_t rows, uint32_t cols, uint32_t k, uint64_t* sidelen) {
+    const uint64_t m = std::max(rows, cols);
+    uint64_t s = 1;
+    uint32_t h = 0;
+    while (s < m) {
+        s *= k;
+        h++;
+    }
+    *sidelen = s;
+    return h;
+}
+constexpr uint64_t kGenericMaxSidelen = 1024;  // universal kernel: level arrays in HBM scratch, ~77 B per node
+
+// returns DCDF_OK and either a fused-kernel class (*generic_key == 0) or the universal kernel's key (k << 8 | H)
+static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls, uint32_t* generic_key) {
+    *generic_key = 0;
     if (!t.base || t.instants == 0 || t.rows == 0 || t.cols == 0) return DCDF_ERR_BAD_ARG;
     if (t.dtype != DCDF_I32 && t.dtype != DCDF_I64 && t.dtype != DCDF_F32 && t.dtype != DCDF_F64) return DCDF_ERR_BAD_ARG;
     if ((t.dtype == DCDF_F32 || t.dtype == DCDF_F64) && t.fractional_bits > 62) return DCDF_ERR_BAD_ARG;
-    if (k != 2) return DCDF_ERR_UNSUPPORTED;
+    if (k < 2 || k > 16) return DCDF_ERR_BAD_ARG;
     const uint32_t lg = sidelen_log2(t.rows, t.cols);
-    if (lg < 3 || lg > 8) return DCDF_ERR_UNSUPPORTED;  // fast path covers sidelen 8..256
+    if (k != 2 || lg < 3 || lg > 8) {  // outside the fused kernel: any k, sidelen 1 .. 1024
+        uint64_t side;
+        const uint32_t H = depth_for(t.rows, t.cols, (uint32_t)k, &side);
+        if (side > kGenericMaxSidelen) return DCDF_ERR_UNSUPPORTED;
+        *generic_key = ((uint32_t)k << 8) | H;
+        return DCDF_OK;
+    }
     const uint32_t S = 1u << lg;
     cls->log2s = (int)lg;
     cls->padded = t.rows != S || t.cols != S;
@@ -113,22 +139,33 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
     e->slot_off.resize(n);
     e->slot_cap.resize(n);
     e->minmax_off.resize(n);
+    e->is_generic.assign(n, 0);
     uint64_t out_total = 0, mm_total = 0;
     for (size_t i = 0; i < n; i++) {
         const dcdf_tile_desc& t = tiles[i];
         EncClass cls{};
-        const int st = validate_tile(t, k, &cls);
+        uint32_t gkey = 0;
+        const int st = validate_tile(t, k, &cls, &gkey);
         e->pre_status[i] = st;
         e->results[i] = TileResult{};
         if (st != DCDF_OK) continue;
-        size_t ci = 0;
-        for (; ci < e->classes.size(); ci++)
-            if (e->classes[ci] == cls) break;
-        if (ci == e->classes.size()) {
-            e->classes.push_back(cls);
-            e->class_tiles.emplace_back();
+        if (gkey) {
+            e->is_generic[i] = 1;
+            size_t gi = 0;
+            for (; gi < e->generic_groups.size(); gi++)
+                if (e->generic_groups[gi].first == gkey) break;
+            if (gi == e->generic_groups.size()) e->generic_groups.emplace_back(gkey, std::vector<uint32_t>());
+            e->generic_groups[gi].second.push_back((uint32_t)i);
+        } else {
+            size_t ci = 0;
+            for (; ci < e->classes.size(); ci++)
+                if (e->classes[ci] == cls) break;
+            if (ci == e->classes.size()) {
+                e->classes.push_back(cls);
+                e->class_tiles.emplace_back();
+            }
+            e->class_tiles[ci].push_back((uint32_t)i);
         }
-        e->class_tiles[ci].push_back((uint32_t)i);
         uint64_t cap = out_cap_per_tile ? out_cap_per_tile : (uint64_t)t.instants * t.rows * t.cols * 4 + 4096;
         cap = (cap + 255) & ~255ull;
         e->slot_off[i] = out_total;
@@ -220,6 +257,56 @@ static int run_classes(dcdf_encoder* e, const std::vector<std::vector<uint32_t>>
     return DCDF_OK;
 }
 
+// The universal kernel over `tiles` (all of one (k, H)); tiles whose slot is too small are re-run into exact-size slots.
+static int run_generic(dcdf_encoder* e, uint32_t key, const std::vector<uint32_t>& tiles, float* ms_acc) {
+    if (tiles.empty()) return DCDF_OK;
+    Runtime& rt = Runtime::get();
+    const uint32_t k = key >> 8, H = key & 0xffu;
+    const uint64_t per_wg = (generic_scratch_bytes(k, H) + 255) & ~255ull;
+    const uint64_t budget = 8ull << 30;
+    const size_t n = e->desc.size();
+    std::vector<uint32_t> todo(tiles);
+    for (int pass = 0; pass < 2 && !todo.empty(); pass++) {
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)todo.size(), (uint64_t)rt.cus, budget / per_wg}));
+        DevBuf d_scratch, d_order, d_queue;
+        K2R_HIP(d_scratch.alloc((size_t)grid * per_wg));
+        K2R_HIP(d_order.alloc(todo.size() * 4));
+        K2R_HIP(d_queue.alloc(4));
+        K2R_HIP(hipMemcpyAsync(d_order.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, e->stream));
+        K2R_HIP(hipMemsetAsync(d_queue.p, 0, 4, e->stream));
+        EncodeLaunch L{};
+        L.tiles = e->d_args.as<TileArgs>();
+        L.results = e->d_results.as<TileResult>();
+        L.order = d_order.as<uint32_t>();
+        L.n = (uint32_t)todo.size();
+        L.queue = d_queue.as<uint32_t>();
+        L.lists = nullptr;
+        L.grid = grid;
+        K2R_HIP(hipEventRecord(e->ev0, e->stream));
+        K2R_HIP(launch_encode_generic(L, d_scratch.as<uint8_t>(), per_wg, k, H, e->stream));
+        K2R_HIP(hipEventRecord(e->ev1, e->stream));
+        K2R_HIP(hipStreamSynchronize(e->stream));
+        float ms = 0.f;
+        K2R_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        if (ms_acc) *ms_acc += ms;
+        K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> again;
+        for (uint32_t ti : todo)
+            if (e->results[ti].status == ST_OUT_CAPACITY && pass == 0) {  // res.len = the bytes it needs
+                const uint64_t cap = (e->results[ti].len + 255) & ~255ull;
+                std::unique_ptr<DevBuf> b(new DevBuf());
+                K2R_HIP(b->alloc(cap));
+                e->args[ti].out = b->as<uint8_t>();
+                e->args[ti].out_cap = cap;
+                e->retry_slots.push_back(std::move(b));
+                K2R_HIP(hipMemcpy(e->d_args.as<TileArgs>() + ti, &e->args[ti], sizeof(TileArgs), hipMemcpyHostToDevice));
+                again.push_back(ti);
+            }
+        todo.swap(again);
+    }
+    return DCDF_OK;
+}
+
 extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
     if (!e) return DCDF_ERR_BAD_ARG;
     const size_t n = e->desc.size();
@@ -272,6 +359,29 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
             K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], e->class_tiles[ci].data(),
                               e->class_tiles[ci].size() * 4, hipMemcpyHostToDevice));
     }
+    // The universal kernel: tiles outside the fused kernel's shapes, then the tiles the fused kernel declined at run time
+    // (a stored value beyond its 2^30 contract: ST_UNSUPPORTED) -- same slot, retried with an exact-size one if need be.
+    float gen_ms = 0.f;
+    for (const auto& g : e->generic_groups) {
+        rc = run_generic(e, g.first, g.second, &gen_ms);
+        if (rc != DCDF_OK) return rc;
+    }
+    std::vector<std::pair<uint32_t, std::vector<uint32_t>>> declined;
+    for (size_t ci = 0; ci < e->classes.size(); ci++)
+        for (uint32_t ti : e->class_tiles[ci])
+            if (e->results[ti].status == ST_UNSUPPORTED) {
+                const uint32_t key = (2u << 8) | (uint32_t)e->classes[ci].log2s;
+                size_t gi = 0;
+                for (; gi < declined.size(); gi++)
+                    if (declined[gi].first == key) break;
+                if (gi == declined.size()) declined.emplace_back(key, std::vector<uint32_t>());
+                declined[gi].second.push_back(ti);
+            }
+    for (const auto& g : declined) {
+        rc = run_generic(e, g.first, g.second, &gen_ms);
+        if (rc != DCDF_OK) return rc;
+    }
+    if (kernel_ms) *kernel_ms += gen_ms;
     return DCDF_OK;
 }
 
@@ -675,7 +785,7 @@ extern "C" const char* dcdf_strerror(int code) {
         case DCDF_ERR_BOUNDS: return "query out of bounds";
         case DCDF_ERR_TOO_MANY_LOGS: return "too many logs in one block (block.rs:27-32)";
         case DCDF_ERR_FORMAT: return "malformed encoded chunk";
-        case DCDF_ERR_UNSUPPORTED: return "unsupported by the MI355X fast path (k != 2, sidelen outside 8..256, or |value| >= 2^30)";
+        case DCDF_ERR_UNSUPPORTED: return "unsupported: sidelen above 1024 outside the fused kernel (k = 2, sidelen 8..256)";
         case DCDF_ERR_NO_DEVICE: return "no usable gfx950 device / HIP failure";
         case DCDF_ERR_NOMEM: return "out of memory";
         case DCDF_ERR_CAPACITY: return "result buffer too small";

@@ -24,6 +24,10 @@ struct EncodeLaunch {
 };
 
 hipError_t launch_encode(const EncClass& cls, const EncodeLaunch& L, hipStream_t stream);
+// the universal encoder (k2r_generic.hip): any k, sidelen = k^H, full int64 values; one workgroup per tile, `scratch_per_wg`
+// bytes of global scratch each (generic_scratch_bytes)
+hipError_t launch_encode_generic(const EncodeLaunch& L, uint8_t* scratch, uint64_t scratch_per_wg, uint32_t k, uint32_t H, hipStream_t stream);
+uint64_t generic_scratch_bytes(uint32_t k, uint32_t H);
 int encode_blocks_per_cu(const EncClass& cls);
 size_t encode_list_words(const EncClass& cls);
 int encode_threads(const EncClass& cls);

@@ -142,13 +142,15 @@ def test_254_log_cap(dc):  # chunk.rs:62, block.rs:27
     assert_same(dc, [a])
 
 
-def test_unsupported_inputs_are_reported(dc):
+def test_inputs_outside_the_fused_kernel_take_the_universal_one(dc):
+    """|v| >= 2^30, sidelen < 8 or > 256, k = 3: declined by the fused kernel, encoded by k2r_generic.hip (more in
+    tests/test_gpu_generic.py)."""
     a = np.zeros((2, 8, 8), dtype=np.int64)
     a[1, 3, 3] = 2 ** 30
-    r = dc.build_batch([a, np.zeros((2, 4, 4), dtype=np.int32), np.zeros((1, 300, 8), dtype=np.int32)])
-    assert all(isinstance(x, Exception) and x.code == -8 for x in r)
-    with pytest.raises(dc.DcdfError):
-        dc.Chunk.build(np.zeros((2, 8, 8), dtype=np.int32), k=3)
+    assert_same(dc, [a, np.zeros((2, 4, 4), dtype=np.int32), np.zeros((1, 300, 8), dtype=np.int32)])
+    b = np.arange(2 * 9 * 9, dtype=np.int32).reshape(2, 9, 9) % 7
+    r = dc.Chunk.build(b, k=3)
+    assert r.data.write_to() == O.chunk_build(b, k=3)
 
 
 def test_config2_sample_synthetic_256(dc):
@@ -182,16 +184,14 @@ def test_float32_full_size_chunks(dc):
     r = dc.build_batch([g], fractional_bits=3)[0]
     assert isinstance(r, Exception) and r.code == -3
     assert_same(dc, [g], fractional_bits=3, round=True)
-    g[2, 9, 9] = np.float32(3e8)
-    r = dc.build_batch([g], fractional_bits=3)[0]
-    assert isinstance(r, Exception) and r.code == -8
+    g[2, 9, 9] = np.float32(3e8)  # stored value beyond 2^30: the universal kernel takes the tile
+    assert_same(dc, [g], fractional_bits=3, round=True)
 
 
 def test_int32_rows_value_range_contract(dc):
     a = np.zeros((2, 16, 16), dtype=np.int32)
-    a[1, 9, 9] = 2 ** 30
-    r = dc.build_batch([a])[0]
-    assert isinstance(r, Exception) and r.code == -8
+    a[1, 9, 9] = 2 ** 30  # outside the fused kernel's contract: re-routed, same bytes as the oracle
+    assert_same(dc, [a])
     a[1, 9, 9] = 2 ** 30 - 1
     a[0, 1, 1] = -(2 ** 30)
     assert_same(dc, [a])
@@ -223,9 +223,10 @@ from dcdf_amd.encoder import Encoder
 rng = np.random.default_rng(9)
 arrays = [rng.integers(-50, 50, size=(t, s, s)).astype(np.int32) for t, s in ((1, 8), (2, 8), (3, 16), (5, 32), (7, 64), (4, 128))]
 arrays += [np.zeros((1, 8, 8), dtype=np.int32), synth.cells(0xDCDF0005, 0, 6, 0, 256, 0, 256, np.int32)]
-bad = np.zeros((2, 8, 8), dtype=np.int32)
-bad[1, 1, 1] = 2 ** 30  # outside the fast path: fails, digest stays zero
-arrays.append(bad)
+wide = np.zeros((2, 8, 8), dtype=np.int32)
+wide[1, 1, 1] = 2 ** 30  # outside the fused kernel's contract: encoded by the universal kernel, hashed like the others
+arrays.append(wide)
+arrays.append(np.zeros((1, 1500, 8), dtype=np.int32))  # sidelen 2048: refused, digest stays zero
 dev = [torch.from_numpy(a).cuda() for a in arrays]
 enc = Encoder([(d.data_ptr(), L.DCDF_I32, tuple(s // 4 for s in a.strides), a.shape) for d, a in zip(dev, arrays)], k=2)
 enc.run()
