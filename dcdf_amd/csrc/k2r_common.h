@@ -99,7 +99,13 @@ K2R_HD void store_be32(uint8_t* p, uint32_t w) {
     p[3] = (uint8_t)w;
 }
 K2R_HD uint32_t load_be32(const uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one (possibly unaligned) 4-byte load + byte swap instead of four byte loads: the serialized stream has no alignment
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    return __builtin_bswap32(*(const u32_unaligned*)p);
+#else
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+#endif
 }
 
 }  // namespace k2r

@@ -126,6 +126,209 @@ k_fill_window(const ChunkRef* __restrict__ chunks, const WinQuery* __restrict__ 
     }
 }
 
+
+// ---- wave-cooperative window decode ---------------------------------------------------------------------------------------
+// fill_window the MI355X way: one WAVE per (query, instant, sub-window of at most 32 x 32 cells) walks the nodes that
+// cover the sub-window ONCE, level by level (snapshot.rs:237-301, log.rs:349-508 are depth-first recursions over the same
+// nodes): lane = (frontier node, child).  A node's rank / Dac hops are paid once per node instead of once per cell; the
+// frontier lives in LDS and is compacted with ballot + mbcnt; uniform or "equal" subtrees become rectangle fills done by
+// the whole wave; the last two levels (a node of side k and its cells) are finished by the lane that owns the node.
+struct WinItem {
+    uint32_t chunk, inst;
+    uint16_t top, bottom, left, right;  // sub-window, chunk coordinates, half-open
+    uint32_t out_sr;                     // output row stride in elements (column stride 1)
+    uint64_t out_off;                    // element offset of cell (top, left) of this instant in `out`
+};
+constexpr int WQ_CAP = 192;             // frontier entries per wave: nodes of side >= k^2 meeting a 32 x 32 window, all levels
+constexpr uint32_t WQ_NONE = 0xffffffffu;
+struct WaveQ {
+    uint32_t it[WQ_CAP], is[WQ_CAP], org[WQ_CAP];  // first child of the node in the log / snapshot tree (or NONE), origin row << 16 | col
+    int64_t mt[WQ_CAP], ms[WQ_CAP];                 // log.rs:360-361 max_t, max_s
+};
+struct NodeSt {
+    uint32_t bt, bs;  // index of the node's FIRST CHILD in the log / snapshot tree (1 + rank(T, node) * k^2), or NONE
+    int64_t mt, ms;   // log.rs:360-361 max_t, max_s
+};
+// One step of the synchronized descent (log.rs:392-505; snapshot.rs:281-299 when there is no log): child c of a node.
+// Returns true when the child's whole square has one value (*val), else the child's state in *o.  The rank that locates
+// the child's own children is computed HERE, next to the child's other loads (they are independent of each other), so that
+// the next level does not start with a round trip of its own.
+__device__ __forceinline__ bool window_child(const uint8_t* b, const InstDesc& S, const InstDesc* L, const NodeSt& p, uint32_t c,
+                                             uint32_t k2, NodeSt* o, int64_t* val) {
+    const bool has_t = p.bt != WQ_NONE, has_s = p.bs != WQ_NONE;
+    const uint32_t it_ = has_t ? p.bt + c : 0u, is_ = has_s ? p.bs + c : 0u;
+    const int64_t mt_ = has_t ? dacd_get(b, L->mx, it_) : p.mt;             // log.rs:397-400
+    const int64_t ms_ = has_s ? p.ms - dacd_get(b, S.mx, is_) : p.ms;       // log.rs:412-415
+    const bool leaf_t = has_t ? (it_ >= L->T.len || !bmd_get(b, L->T, it_)) : true;
+    const bool leaf_s = has_s ? (is_ >= S.T.len || !bmd_get(b, S.T, is_)) : true;
+    const uint32_t rt = has_t ? bmd_rank(b, L->T, it_) : 0u, rs = has_s ? bmd_rank(b, S.T, is_) : 0u;
+    *val = mt_ + ms_;
+    if (leaf_t && leaf_s) return true;
+    o->mt = mt_;
+    o->ms = ms_;
+    if (leaf_s) {
+        o->bt = 1 + rt * k2;
+        o->bs = WQ_NONE;
+        return false;
+    }
+    if (leaf_t) {
+        // rank0(T, it_ + 1) - 1 with T[it_] == 0 is it_ - rank(T, it_)
+        if (has_t && !bmd_get(b, L->E, it_ - rt)) return true;  // uniform, not "equal" (log.rs:452-467)
+        o->bt = WQ_NONE;
+        o->bs = 1 + rs * k2;
+        return false;
+    }
+    o->bt = 1 + rt * k2;
+    o->bs = 1 + rs * k2;
+    return false;
+}
+
+__global__ void __launch_bounds__(256)
+k_window_wave(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ items, uint32_t n_items, void* out, int32_t out_dtype) {
+    __shared__ WaveQ wq[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveQ& q = wq[wave];
+    for (uint32_t item = blockIdx.x * 4u + (uint32_t)wave; item < n_items; item += gridDim.x * 4u) {
+        const WinItem I = items[item];
+        const ChunkRef C = chunks[I.chunk];
+        const uint8_t* const b = C.bytes;
+        const InstDesc& D = C.descs[I.inst];
+        const bool has_log = D.is_log != 0;
+        const InstDesc& S = has_log ? C.descs[D.snap] : D;
+        const InstDesc* const L = has_log ? &D : nullptr;
+        const uint32_t k = D.k, k2 = k * k;
+        const uint32_t wtop = I.top, wbot = I.bottom, wleft = I.left, wright = I.right;
+        auto put = [&](uint32_t r, uint32_t c, int64_t v) {
+            store_typed(out, (int64_t)I.out_off + (int64_t)(r - wtop) * I.out_sr + (c - wleft), out_dtype, v, C.fbits);
+        };
+        // rectangle [r0, r1) x [c0, c1) (already clipped to the sub-window) <- v, by the whole wave
+        auto fill_wave = [&](uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int64_t v) {
+            const uint32_t w = c1 - c0, area = (r1 - r0) * w;
+            for (uint32_t i = (uint32_t)lane; i < area; i += 64) put(r0 + i / w, c0 + i % w, v);
+        };
+        // ---- roots (snapshot.rs:211-219, log.rs:315-328) ----
+        const bool single_s = !bmd_get(b, S.T, 0);
+        const bool single_t = has_log ? !bmd_get(b, L->T, 0) : true;
+        const int64_t max_s0 = dacd_get(b, S.mx, 0), max_t0 = has_log ? dacd_get(b, L->mx, 0) : 0;
+        const bool all_one = has_log ? (single_t && (single_s || !bmd_get(b, L->E, 0))) : single_s;
+        if (all_one) {
+            fill_wave(wtop, wbot, wleft, wright, max_t0 + max_s0);
+            continue;
+        }
+        if (lane == 0) {
+            q.it[0] = (has_log && !single_t) ? 1u : WQ_NONE;  // children of the root start at 1 (rank(T, 0) == 0)
+            q.is[0] = single_s ? WQ_NONE : 1u;
+            q.org[0] = 0;
+            q.mt[0] = max_t0;
+            q.ms[0] = max_s0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t lo = 0, hi = 1, side = D.sidelen;
+        const uint32_t per = 64u / k2;  // frontier nodes per step (lane = node * k2 + child)
+        const uint32_t myn = (uint32_t)lane / k2, myc = (uint32_t)lane % k2;
+        // ---- level by level while the children are still at least k x k ----
+        while (side > k2) {
+            const uint32_t cs = side / k;
+            uint32_t next = hi;
+            for (uint32_t base = lo; base < hi; base += per) {
+                const uint32_t n = base + myn;
+                const bool live = myn < per && n < hi;
+                bool push = false, fill = false;
+                NodeSt o{};
+                int64_t val = 0;
+                uint32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, org = 0;
+                if (live) {
+                    const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+                    const uint32_t po = q.org[n];
+                    const uint32_t cr = (po >> 16) + (myc / k) * cs, cc = (po & 0xffffu) + (myc % k) * cs;
+                    r0 = cr > wtop ? cr : wtop; r1 = cr + cs < wbot ? cr + cs : wbot;
+                    c0 = cc > wleft ? cc : wleft; c1 = cc + cs < wright ? cc + cs : wright;
+                    if (r0 < r1 && c0 < c1) {
+                        fill = window_child(b, S, L, p, myc, k2, &o, &val);
+                        push = !fill;
+                        org = (cr << 16) | cc;
+                    }
+                }
+                const unsigned long long bp = __builtin_amdgcn_ballot_w64(push);
+                if (push) {
+                    const uint32_t pos = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bp, 0u));
+                    if (pos < (uint32_t)WQ_CAP) {
+                        q.it[pos] = o.bt; q.is[pos] = o.bs; q.org[pos] = org; q.mt[pos] = o.mt; q.ms[pos] = o.ms;
+                    }
+                }
+                next += (uint32_t)__builtin_popcountll(bp);
+                // fills: small ones by their lane, the others by the wave
+                const bool small = (r1 - r0) * (c1 - c0) <= 4;
+                if (fill && small)
+                    for (uint32_t r = r0; r < r1; r++)
+                        for (uint32_t c = c0; c < c1; c++) put(r, c, val);
+                unsigned long long bf = __builtin_amdgcn_ballot_w64(fill && !small);
+                while (bf) {
+                    const int l = __builtin_ctzll(bf);
+                    bf &= bf - 1;
+                    const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)((r0 << 16) | r1), l);
+                    const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)((c0 << 16) | c1), l);
+                    const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)val, l);
+                    const uint32_t vhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)val >> 32), l);
+                    fill_wave(rr >> 16, rr & 0xffffu, cc >> 16, cc & 0xffffu, (int64_t)(((uint64_t)vhi << 32) | vlo));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            lo = hi;
+            hi = next < (uint32_t)WQ_CAP ? next : (uint32_t)WQ_CAP;  // (cannot overflow for sub-windows of <= 32 x 32: see the host)
+            side = cs;
+        }
+        // ---- the last two levels: lane = (node of side <= k^2, child); the child's cells are finished by the lane ----
+        {
+            const uint32_t cs = side / k;  // k (then the grandchildren are cells) or 1 (the children are cells)
+            for (uint32_t base = lo; base < hi; base += per) {
+                const uint32_t n = base + myn;
+                if (!(myn < per && n < hi)) continue;
+                const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+                const uint32_t po = q.org[n];
+                const uint32_t cr = (po >> 16) + (myc / k) * cs, cc = (po & 0xffffu) + (myc % k) * cs;
+                const uint32_t r0 = cr > wtop ? cr : wtop, r1 = cr + cs < wbot ? cr + cs : wbot;
+                const uint32_t c0 = cc > wleft ? cc : wleft, c1 = cc + cs < wright ? cc + cs : wright;
+                if (!(r0 < r1 && c0 < c1)) continue;
+                NodeSt o{};
+                int64_t val = 0;
+                const bool fill = window_child(b, S, L, p, myc, k2, &o, &val);
+                if (fill || cs == 1) {  // (a cell is always a leaf of both trees)
+                    for (uint32_t r = r0; r < r1; r++)
+                        for (uint32_t c = c0; c < c1; c++) put(r, c, val);
+                    continue;
+                }
+                if (cs != k) {  // sidelen not a power of k (malformed input): plain per-cell descents
+                    for (uint32_t r = r0; r < r1; r++)
+                        for (uint32_t c = c0; c < c1; c++) put(r, c, inst_get(b, C.descs, I.inst, r, c));
+                    continue;
+                }
+                if (k == 2) {  // the four cells at once: their loads are independent of each other
+                    int64_t v[4];
+                    NodeSt oo{};
+#pragma unroll
+                    for (int g = 0; g < 4; g++) (void)window_child(b, S, L, o, (uint32_t)g, k2, &oo, &v[g]);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const uint32_t r = cr + (uint32_t)(g >> 1), c = cc + (uint32_t)(g & 1);
+                        if (r >= r0 && r < r1 && c >= c0 && c < c1) put(r, c, v[g]);
+                    }
+                    continue;
+                }
+                for (uint32_t r = r0; r < r1; r++)
+                    for (uint32_t c = c0; c < c1; c++) {
+                        NodeSt oo{};
+                        int64_t v = 0;
+                        (void)window_child(b, S, L, o, (r - cr) * k + (c - cc), k2, &oo, &v);
+                        put(r, c, v);
+                    }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // get / fill_cell: one thread per (query) point
 struct PointQuery {
     uint32_t chunk, instant, row, col;
@@ -287,6 +490,45 @@ extern "C" int dcdf_chunk_fill_cell(const dcdf_chunk* h, uint32_t start, uint32_
     return run_points(h, pq, out);
 }
 
+
+// (query, instant, sub-window) items of the wave kernel: sub-windows are the 32 x 32 squares of the chunk's grid that the
+// window meets, so that a frontier level never exceeds what a wave's LDS queue holds (k2r::WQ_CAP)
+static void window_items(uint32_t chunk, const dcdf_cube& c, uint64_t out_base, std::vector<WinItem>& items) {
+    const uint64_t wr = c.bottom - c.top, wc = c.right - c.left;
+    for (uint32_t t = c.start; t < c.end; t++)
+        for (uint32_t r = c.top & ~31u; r < c.bottom; r += 32)
+            for (uint32_t cc = c.left & ~31u; cc < c.right; cc += 32) {
+                WinItem it{};
+                it.chunk = chunk;
+                it.inst = t;
+                it.top = (uint16_t)std::max(r, c.top);
+                it.bottom = (uint16_t)std::min(r + 32, c.bottom);
+                it.left = (uint16_t)std::max(cc, c.left);
+                it.right = (uint16_t)std::min(cc + 32, c.right);
+                it.out_sr = (uint32_t)wc;
+                it.out_off = out_base + ((uint64_t)(t - c.start) * wr + (it.top - c.top)) * wc + (it.left - c.left);
+                items.push_back(it);
+            }
+}
+// the wave kernel handles k * k <= 64 children per node and 16-bit coordinates
+static bool wave_kernel_ok(const dcdf_chunk* h) {
+    const uint32_t k = h->descs[0].k;
+    return k * k <= 64 && h->descs[0].sidelen <= 65535;
+}
+static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>& items, void* d_out, int32_t dtype, hipEvent_t e0, hipEvent_t e1) {
+    DevBuf d_items;
+    K2R_HIP(d_items.alloc(items.size() * sizeof(WinItem)));
+    K2R_HIP(hipMemcpy(d_items.p, items.data(), items.size() * sizeof(WinItem), hipMemcpyHostToDevice));
+    const uint32_t n = (uint32_t)items.size();
+    const uint32_t grid = std::min<uint32_t>((n + 3) / 4, 256u * 16u);
+    if (e0) K2R_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_window_wave, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+    if (e1) K2R_HIP(hipEventRecord(e1, 0));
+    K2R_HIP(hipGetLastError());
+    K2R_HIP(hipDeviceSynchronize());
+    return DCDF_OK;
+}
+
 // ---- windows ----------------------------------------------------------------------------------------------
 extern "C" int dcdf_chunk_fill_window(const dcdf_chunk* h, const dcdf_cube* cube, void* out, int32_t out_dtype,
                                       int64_t stride_t, int64_t stride_r, int64_t stride_c) {
@@ -308,9 +550,16 @@ extern "C" int dcdf_chunk_fill_window(const dcdf_chunk* h, const dcdf_cube* cube
     K2R_HIP(d_q.alloc(sizeof(q)));
     K2R_HIP(hipMemcpy(d_q.p, &q, sizeof(q), hipMemcpyHostToDevice));
     K2R_HIP(d_o.alloc(wt * wr * wc * es));
-    hipLaunchKernelGGL(k_fill_window, dim3(1), dim3(256), 0, 0, d_ref.as<ChunkRef>(), d_q.as<WinQuery>(), 1u, d_o.p,
-                       out_dtype, (int64_t)(wr * wc), (int64_t)wc, (int64_t)1, 1);
-    K2R_HIP(hipGetLastError());
+    if (wave_kernel_ok(h)) {
+        std::vector<WinItem> items;
+        window_items(0, c, 0, items);
+        const int rc = launch_window_items(d_ref, items, d_o.p, out_dtype, nullptr, nullptr);
+        if (rc != DCDF_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(k_fill_window, dim3(1), dim3(256), 0, 0, d_ref.as<ChunkRef>(), d_q.as<WinQuery>(), 1u, d_o.p,
+                           out_dtype, (int64_t)(wr * wc), (int64_t)wc, (int64_t)1, 1);
+        K2R_HIP(hipGetLastError());
+    }
     std::vector<uint8_t> dense(wt * wr * wc * es);
     K2R_HIP(hipMemcpy(dense.data(), d_o.p, dense.size(), hipMemcpyDeviceToHost));
     const bool contiguous = stride_c == 1 && stride_r == (int64_t)wc && stride_t == (int64_t)(wr * wc);
@@ -492,12 +741,24 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
     K2R_HIP(d_o.alloc(total * 8));
     EventPair ev;
     K2R_HIP(ev.create());
-    const uint32_t grid = (uint32_t)std::min<size_t>(nq, 1u << 20);
-    K2R_HIP(hipEventRecord(ev.e0, 0));
-    hipLaunchKernelGGL(k_fill_window, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
-                       (uint32_t)nq, d_o.p, (int32_t)DCDF_I64, (int64_t)0, (int64_t)0, (int64_t)0, 0);
-    K2R_HIP(hipEventRecord(ev.e1, 0));
-    K2R_HIP(hipGetLastError());
+    bool all_wave = true;
+    for (const dcdf_chunk* u : uniq) all_wave = all_wave && wave_kernel_ok(u);
+    if (all_wave) {
+        std::vector<WinItem> items;
+        for (size_t q = 0; q < nq; q++) {
+            const dcdf_cube c{qs[q].start, qs[q].end, qs[q].top, qs[q].bottom, qs[q].left, qs[q].right};
+            window_items(qs[q].chunk, c, qs[q].out_off, items);
+        }
+        rc = launch_window_items(d_refs, items, d_o.p, (int32_t)DCDF_I64, ev.e0, ev.e1);
+        if (rc != DCDF_OK) return rc;
+    } else {
+        const uint32_t grid = (uint32_t)std::min<size_t>(nq, 1u << 20);
+        K2R_HIP(hipEventRecord(ev.e0, 0));
+        hipLaunchKernelGGL(k_fill_window, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
+                           (uint32_t)nq, d_o.p, (int32_t)DCDF_I64, (int64_t)0, (int64_t)0, (int64_t)0, 0);
+        K2R_HIP(hipEventRecord(ev.e1, 0));
+        K2R_HIP(hipGetLastError());
+    }
     if (dense) {  // the usual case: windows back to back in query order -> one copy straight into the caller's array
         K2R_HIP(hipMemcpy(out + out_offset[0], d_o.p, total * 8, hipMemcpyDeviceToHost));
     } else {

@@ -72,7 +72,7 @@ def test_random_unpadded(shape, kind):
 
 
 @pytest.mark.parametrize("rows,cols", [(5, 3), (8, 7), (9, 9), (16, 9), (17, 4), (13, 31), (33, 20), (64, 1), (100, 77),
-                                       (129, 130), (7, 8)])
+                                       (129, 130), (7, 8), (200, 256), (256, 255)])
 def test_padded_shapes(rows, cols):
     rng = np.random.default_rng(rows * 1000 + cols)
     a = rng.integers(-9, 9, size=(5, rows, cols)).astype(np.int64)
