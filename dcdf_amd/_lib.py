@@ -21,6 +21,15 @@ class Encoded(C.Structure):
                 ("status", C.c_int32), ("_pad", C.c_int32), ("minmax", C.POINTER(C.c_int64))]
 
 
+class StoredObject(C.Structure):
+    _fields_ = [("cid", C.c_uint8 * 36), ("bytes", C.POINTER(C.c_uint8)), ("len", C.c_size_t)]
+
+
+class SuperchunkBuild(C.Structure):
+    _fields_ = [("objects", C.POINTER(StoredObject)), ("n_objects", C.c_size_t), ("size", C.c_uint64), ("elided", C.c_uint32),
+                ("local", C.c_uint32), ("external", C.c_uint32), ("snapshots", C.c_uint32), ("logs", C.c_uint32)]
+
+
 class Cube(C.Structure):
     _fields_ = [("start", C.c_uint32), ("end", C.c_uint32), ("top", C.c_uint32), ("bottom", C.c_uint32),
                 ("left", C.c_uint32), ("right", C.c_uint32)]
@@ -42,7 +51,7 @@ _lib = None
 # every symbol include/dcdf_k2r.h declares
 SYMBOLS = [
     "dcdf_chunk_build_batch", "dcdf_chunk_build", "dcdf_free_encoded", "dcdf_encoder_create", "dcdf_encoder_run",
-    "dcdf_encoder_result", "dcdf_encoder_fetch", "dcdf_encoder_gather_size", "dcdf_encoder_gather", "dcdf_encoder_total_bytes", "dcdf_encoder_destroy", "dcdf_chunk_open",
+    "dcdf_encoder_result", "dcdf_encoder_fetch", "dcdf_encoder_gather_size", "dcdf_encoder_gather", "dcdf_encoder_total_bytes", "dcdf_encoder_destroy", "dcdf_superchunk_build", "dcdf_free_superchunk", "dcdf_chunk_open",
     "dcdf_chunk_close", "dcdf_chunk_info", "dcdf_chunk_get", "dcdf_chunk_fill_cell", "dcdf_chunk_fill_window",
     "dcdf_chunk_search", "dcdf_query_fill_window_batch", "dcdf_query_search_batch", "dcdf_suggest_fraction", "dcdf_encoder_object_sha256",
     "dcdf_synth_fill", "dcdf_calib_read", "dcdf_device_alloc", "dcdf_device_free", "dcdf_device_copy", "dcdf_strerror", "dcdf_device_name", "dcdf_abi_version", "dcdf_last_hip_error",
@@ -67,6 +76,8 @@ def lib():
         L.dcdf_encoder_destroy.restype = None
         L.dcdf_chunk_close.argtypes = [C.c_void_p]
         L.dcdf_chunk_close.restype = None
+        L.dcdf_free_superchunk.argtypes = [C.c_void_p]
+        L.dcdf_free_superchunk.restype = None
         _lib = L
     return _lib
 

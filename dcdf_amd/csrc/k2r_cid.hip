@@ -100,6 +100,49 @@ __global__ void __launch_bounds__(64) k_object_sha256(const TileArgs* __restrict
     }
 }
 
+// SHA-256 of whole buffers (objects that already carry their header: Links and Superchunk nodes, framed chunk objects):
+// buffer i = data[offs[i] .. offs[i] + lens[i])
+__global__ void __launch_bounds__(64) k_sha256_buffers(const uint8_t* __restrict__ data, const uint64_t* __restrict__ offs,
+                                                       const uint64_t* __restrict__ lens, uint32_t n, uint8_t* __restrict__ digests) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n) return;
+    const uint8_t* m = data + offs[t];
+    const uint64_t total = lens[t];
+    const uint64_t nblk = (total + 1 + 8 + 63) / 64;
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    for (uint64_t b = 0; b < nblk; b++) {
+        uint32_t w[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t i = 64 * b + 4 * j + q;
+                x = (x << 8) | (i < total ? (uint32_t)m[i] : (i == total ? 0x80u : 0u));
+            }
+            w[j] = x;
+        }
+        if (b == nblk - 1) {
+            const uint64_t bits = total * 8;
+            w[14] = (uint32_t)(bits >> 32);
+            w[15] = (uint32_t)bits;
+        }
+        sha256_block(h, w);
+    }
+    uint8_t* out = digests + 32ull * t;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (uint8_t)(h[i] >> 24);
+        out[4 * i + 1] = (uint8_t)(h[i] >> 16);
+        out[4 * i + 2] = (uint8_t)(h[i] >> 8);
+        out[4 * i + 3] = (uint8_t)h[i];
+    }
+}
+hipError_t launch_sha256_buffers(const uint8_t* data, const uint64_t* offs, const uint64_t* lens, uint32_t n, uint8_t* digests, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sha256_buffers, dim3((n + 63) / 64), dim3(64), 0, stream, data, offs, lens, n, digests);
+    return hipGetLastError();
+}
+
 hipError_t launch_object_sha256(const TileArgs* tiles, const TileResult* results, uint32_t n, uint8_t* digests, hipStream_t stream) {
     hipLaunchKernelGGL(k_object_sha256, dim3((n + 63) / 64), dim3(64), 0, stream, tiles, results, n, digests);
     return hipGetLastError();

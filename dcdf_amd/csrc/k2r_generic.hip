@@ -432,6 +432,19 @@ k_encode_generic(const TileArgs* __restrict__ tiles, TileResult* __restrict__ re
     }
 }
 
+// Dac::from(values).write_to (dac.rs:37-44,101-131) for a caller-supplied array: one workgroup; out_len[0] = bytes written.
+// Used by the superchunk assembly for its instant-major min / max Dacs (superchunk.rs:190-198,246-247).
+__global__ void __launch_bounds__(GEN_NT) k_dac_pack(const int64_t* __restrict__ values, uint64_t n, uint8_t* __restrict__ out,
+                                                     uint8_t* __restrict__ tmp, uint64_t* __restrict__ out_len) {
+    __shared__ GenShared sh;
+    const uint64_t len = gen_write_dac(sh, values, n, out, tmp);
+    if (threadIdx.x == 0) out_len[0] = len;
+}
+hipError_t launch_dac_pack(const int64_t* values, uint64_t n, uint8_t* out, uint8_t* tmp, uint64_t* out_len, hipStream_t stream) {
+    hipLaunchKernelGGL(k_dac_pack, dim3(1), dim3(GEN_NT), 0, stream, values, n, out, tmp, out_len);
+    return hipGetLastError();
+}
+
 hipError_t launch_encode_generic(const EncodeLaunch& L, uint8_t* scratch, uint64_t scratch_per_wg, uint32_t k, uint32_t H, hipStream_t stream) {
     hipLaunchKernelGGL(k_encode_generic, dim3(L.grid), dim3(GEN_NT), 0, stream, L.tiles, L.results, L.order, L.n, L.queue, scratch,
                        scratch_per_wg, k, H);

@@ -1,0 +1,492 @@
+// k2r_superchunk.hip -- Superchunk assembly around the chunk encoder: the direct caller of the hot path.
+//
+// Replaces `Superchunk::build(resolver, buffer, shape, levels, k)` (superchunk.rs:88-270) up to, but not including, the
+// store: it returns every object the reference would hand to `resolver.save` -- the framed sub-chunks (resolver.rs:126-138,
+// mmstruct.rs:215-218), nested Superchunk nodes, the `Links` node (links.rs:65-76) -- each with its CID (testing.rs:172-183:
+// CIDv1, codec 0x12, sha2-256), de-duplicated exactly as `external_references` does (superchunk.rs:199-235), and last the
+// Superchunk node itself (superchunk.rs:672-706), byte for byte.
+//
+// Where the work happens:
+//   * per-tile per-instant (min, max) -- MMBuffer3::min_max, mmbuffer.rs:366-499, the float variant's NaN behaviour
+//     included -- one workgroup per (tile, instant) on the device: `k_tile_minmax`;
+//   * uniform-tile elision, the reference table and the recursion into nested superchunks: host control flow on those
+//     numbers (superchunk.rs:127-181,207-236);
+//   * per-tile fractional bits (superchunk.rs:167): dcdf_suggest_fraction (device reductions, k2r_suggest.hip);
+//   * Chunk::build of every non-elided bottom tile: ONE batched launch of the encoder (dcdf_chunk_build_batch);
+//   * the instant-major min / max Dacs (superchunk.rs:190-198,246-247): `k_dac_pack` (k2r_generic.hip);
+//   * SHA-256 of every stored object: `k_sha256_buffers` (k2r_cid.hip).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "k2r_encode.h"
+#include "k2r_runtime.h"
+
+namespace k2r {
+hipError_t launch_dac_pack(const int64_t* values, uint64_t n, uint8_t* out, uint8_t* tmp, uint64_t* out_len, hipStream_t stream);
+hipError_t launch_sha256_buffers(const uint8_t* data, const uint64_t* offs, const uint64_t* lens, uint32_t n, uint8_t* digests, hipStream_t stream);
+
+struct MinMaxTile {  // one tile of the superchunk's grid (device view)
+    const void* base;
+    int64_t st, sr, sc;
+    uint32_t rows, cols;
+};
+
+// (min, max) of one instant of one tile as STORED values (mmbuffer.rs:366-395).  Floats follow min_max_float
+// (mmbuffer.rs:466-499): leading NaNs are skipped, a NaN met later makes the minimum NaN for good; the result goes through
+// to_fixed with the buffer's own fractional bits (NaN -> 0).
+__global__ void __launch_bounds__(256) k_tile_minmax(const MinMaxTile* __restrict__ tiles, uint32_t instants, int32_t dtype, uint32_t fbits,
+                                                     uint32_t round, int64_t* __restrict__ out, int32_t* __restrict__ status) {
+    const uint32_t tile = blockIdx.x / instants, inst = blockIdx.x % instants;
+    const MinMaxTile T = tiles[tile];
+    const uint64_t n = (uint64_t)T.rows * T.cols;
+    __shared__ int64_t smn[256], smx[256];
+    __shared__ unsigned long long sfirst[256], slastnan[256];
+    const int tid = (int)threadIdx.x;
+    const bool is_float = dtype == ENC_F32 || dtype == ENC_F64;
+    int64_t mn = INT64_MAX, mx = INT64_MIN;
+    double fmn = INFINITY, fmx = -INFINITY;
+    unsigned long long first = ~0ull, lastnan = 0;  // first non-NaN position; 1 + last NaN position
+    for (uint64_t i = tid; i < n; i += 256) {
+        const int64_t off = (int64_t)inst * T.st + (int64_t)(i / T.cols) * T.sr + (int64_t)(i % T.cols) * T.sc;
+        if (!is_float) {
+            const int64_t v = dtype == ENC_I32 ? (int64_t)((const int32_t*)T.base)[off] : ((const int64_t*)T.base)[off];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        } else {
+            const double v = dtype == ENC_F32 ? (double)((const float*)T.base)[off] : ((const double*)T.base)[off];
+            if (v != v) {
+                lastnan = i + 1 > lastnan ? i + 1 : lastnan;
+            } else {
+                first = i < first ? i : first;
+                fmn = v < fmn ? v : fmn;
+                fmx = v > fmx ? v : fmx;
+            }
+        }
+    }
+    if (is_float) {
+        mn = (int64_t)__double_as_longlong(fmn);
+        mx = (int64_t)__double_as_longlong(fmx);
+    }
+    smn[tid] = mn; smx[tid] = mx; sfirst[tid] = first; slastnan[tid] = lastnan;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t err = 0;
+        if (!is_float) {
+            for (int i = 1; i < 256; i++) {
+                mn = smn[i] < mn ? smn[i] : mn;
+                mx = smx[i] > mx ? smx[i] : mx;
+            }
+        } else {
+            for (int i = 1; i < 256; i++) {
+                const double a = __longlong_as_double(smn[i]), b = __longlong_as_double(smx[i]);
+                fmn = a < fmn ? a : fmn;
+                fmx = b > fmx ? b : fmx;
+                first = sfirst[i] < first ? sfirst[i] : first;
+                lastnan = slastnan[i] > lastnan ? slastnan[i] : lastnan;
+            }
+            const bool all_nan = first == ~0ull;
+            const bool nan_after = !all_nan && lastnan > first + 1;  // a NaN behind the first number (lastnan = its position + 1)
+            const double qn = __longlong_as_double(0x7ff8000000000000ll);
+            const double vmin = (all_nan || nan_after) ? qn : fmn, vmax = all_nan ? qn : fmx;
+            if (dtype == ENC_F32) {
+                mn = to_fixed_dev<float>((float)vmin, fbits, round != 0, err);
+                mx = to_fixed_dev<float>((float)vmax, fbits, round != 0, err);
+            } else {
+                mn = to_fixed_dev<double>(vmin, fbits, round != 0, err);
+                mx = to_fixed_dev<double>(vmax, fbits, round != 0, err);
+            }
+        }
+        out[2ull * blockIdx.x] = mn;
+        out[2ull * blockIdx.x + 1] = mx;
+        if (err) atomicMin(status, err);
+    }
+}
+
+}  // namespace k2r
+
+using namespace k2r;
+
+namespace {
+
+struct Obj {
+    std::string bytes;  // the stored object (header included)
+};
+struct Level {
+    std::string node;  // header + NODE_SUPERCHUNK + body
+    uint64_t size_self = 0, size = 0;
+    uint32_t elided = 0, external = 0, snapshots = 0, logs = 0;
+};
+struct Ctx {
+    int k;
+    std::vector<std::string> objects;            // in save order, de-duplicated
+    std::map<std::string, size_t> by_cid;        // cid -> index in objects
+    std::vector<std::string> cids;
+};
+
+void put_u32(std::string& s, uint32_t v) {
+    const char b[4] = {(char)(v >> 24), (char)(v >> 16), (char)(v >> 8), (char)v};
+    s.append(b, 4);
+}
+std::string header(uint8_t node_type) {  // resolver.rs:130-133
+    std::string s;
+    s.push_back((char)0xDC);
+    s.push_back((char)0xE0);
+    put_u32(s, 1);
+    s.push_back((char)node_type);
+    return s;
+}
+size_t esize(int dtype) { return (dtype == DCDF_I32 || dtype == DCDF_F32) ? 4 : 8; }
+
+// CIDs of a batch of objects: SHA-256 on the device (testing.rs:172-183)
+int hash_objects(const std::vector<const std::string*>& objs, std::vector<std::string>& cids) {
+    cids.clear();
+    if (objs.empty()) return DCDF_OK;
+    std::vector<uint64_t> offs, lens;
+    uint64_t total = 0;
+    for (auto* o : objs) {
+        offs.push_back(total);
+        lens.push_back(o->size());
+        total += (o->size() + 7) & ~7ull;
+    }
+    std::vector<uint8_t> flat(total ? total : 8, 0);
+    for (size_t i = 0; i < objs.size(); i++) std::memcpy(flat.data() + offs[i], objs[i]->data(), objs[i]->size());
+    DevBuf d_data, d_offs, d_lens, d_dig;
+    K2R_HIP(d_data.alloc(flat.size()));
+    K2R_HIP(d_offs.alloc(objs.size() * 8));
+    K2R_HIP(d_lens.alloc(objs.size() * 8));
+    K2R_HIP(d_dig.alloc(objs.size() * 32));
+    K2R_HIP(hipMemcpy(d_data.p, flat.data(), flat.size(), hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_offs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_lens.p, lens.data(), lens.size() * 8, hipMemcpyHostToDevice));
+    K2R_HIP(launch_sha256_buffers(d_data.as<uint8_t>(), d_offs.as<uint64_t>(), d_lens.as<uint64_t>(), (uint32_t)objs.size(), d_dig.as<uint8_t>(), 0));
+    std::vector<uint8_t> dig(objs.size() * 32);
+    K2R_HIP(hipMemcpy(dig.data(), d_dig.p, dig.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < objs.size(); i++) {
+        std::string c("\x01\x12\x12\x20", 4);
+        c.append((const char*)dig.data() + 32 * i, 32);
+        cids.push_back(c);
+    }
+    return DCDF_OK;
+}
+// resolver.save: remember the object under its CID (content addressing makes identical objects one object)
+void save(Ctx& cx, const std::string& cid, const std::string& obj) {
+    if (cx.by_cid.count(cid)) return;
+    cx.by_cid[cid] = cx.objects.size();
+    cx.objects.push_back(obj);
+    cx.cids.push_back(cid);
+}
+// Dac::from(values).write_to on the device
+int dac_bytes(const std::vector<int64_t>& v, std::string& out) {
+    DevBuf d_v, d_out, d_tmp, d_len;
+    const size_t n = v.size();
+    K2R_HIP(d_v.alloc(std::max<size_t>(n, 1) * 8));
+    K2R_HIP(d_out.alloc(1 + 8 * (n + 8 + (n / 128 + 1) * 4 + ((n + 31) / 32) * 4) + 64));
+    K2R_HIP(d_tmp.alloc(n + 16));
+    K2R_HIP(d_len.alloc(8));
+    if (n) K2R_HIP(hipMemcpy(d_v.p, v.data(), n * 8, hipMemcpyHostToDevice));
+    K2R_HIP(launch_dac_pack(d_v.as<int64_t>(), n, d_out.as<uint8_t>(), d_tmp.as<uint8_t>(), d_len.as<uint64_t>(), 0));
+    uint64_t len = 0;
+    K2R_HIP(hipMemcpy(&len, d_len.p, 8, hipMemcpyDeviceToHost));
+    out.resize(len);
+    K2R_HIP(hipMemcpy(&out[0], d_out.p, len, hipMemcpyDeviceToHost));
+    return DCDF_OK;
+}
+uint32_t levels_needed(uint64_t side, int k) {  // superchunk.rs:98-101 (ceil(log_k(side)), exact for our sizes)
+    uint32_t h = 0;
+    uint64_t s = 1;
+    while (s < side) {
+        s *= (uint64_t)k;
+        h++;
+    }
+    return h;
+}
+
+// One Superchunk::build over the DEVICE view `buf` (superchunk.rs:88-270).
+int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size_t n_levels, Level* out) {
+    const int k = cx.k;
+    const uint32_t instants = buf.instants, rows = buf.rows, cols = buf.cols;
+    const uint32_t total_levels = levels_needed(std::max(rows, cols), k);
+    uint32_t user = 0;
+    for (size_t i = 0; i < n_levels; i++) user += levels[i];
+    if (n_levels < 2 || user != total_levels) return DCDF_ERR_BAD_ARG;  // superchunk.rs:104-110 panics
+    uint64_t sidelen = 1;
+    for (uint32_t i = 0; i < total_levels; i++) sidelen *= (uint64_t)k;
+    const uint32_t* sublevels = levels + 1;
+    const size_t n_sub = n_levels - 1;
+    const bool at_bottom = n_sub == 1;
+    uint64_t subsidelen = 1;
+    for (uint32_t i = 0; i < levels[0]; i++) subsidelen *= (uint64_t)k;
+    const uint64_t chunks_sidelen = sidelen / subsidelen;
+    const size_t n_tiles = (size_t)(subsidelen * subsidelen);
+    const size_t es = esize(buf.dtype);
+    // ---- the grid (superchunk.rs:127-142) and its per-instant (min, max) on the device ----
+    std::vector<dcdf_tile_desc> tiles(n_tiles);
+    std::vector<char> inside(n_tiles, 0);
+    std::vector<MinMaxTile> mt;
+    std::vector<size_t> mt_tile;
+    for (uint64_t row = 0; row < subsidelen; row++)
+        for (uint64_t col = 0; col < subsidelen; col++) {
+            const size_t i = (size_t)(row * subsidelen + col);
+            const uint64_t top = row * chunks_sidelen, left = col * chunks_sidelen;
+            if (top >= rows || left >= cols) continue;
+            const uint64_t bottom = std::min<uint64_t>(top + chunks_sidelen, rows), right = std::min<uint64_t>(left + chunks_sidelen, cols);
+            dcdf_tile_desc t = buf;
+            t.base = (const uint8_t*)buf.base + ((int64_t)top * buf.stride_r + (int64_t)left * buf.stride_c) * (int64_t)es;
+            t.rows = (uint32_t)(bottom - top);
+            t.cols = (uint32_t)(right - left);
+            tiles[i] = t;
+            inside[i] = 1;
+            mt.push_back(MinMaxTile{t.base, t.stride_t, t.stride_r, t.stride_c, t.rows, t.cols});
+            mt_tile.push_back(i);
+        }
+    std::vector<int64_t> mm(2ull * n_tiles * instants, 0);  // [tile][instant][2]
+    if (!mt.empty()) {
+        DevBuf d_mt, d_out, d_st;
+        K2R_HIP(d_mt.alloc(mt.size() * sizeof(MinMaxTile)));
+        K2R_HIP(d_out.alloc(mt.size() * instants * 16ull));
+        K2R_HIP(d_st.alloc(4));
+        K2R_HIP(hipMemcpy(d_mt.p, mt.data(), mt.size() * sizeof(MinMaxTile), hipMemcpyHostToDevice));
+        K2R_HIP(hipMemset(d_st.p, 0, 4));
+        hipLaunchKernelGGL(k_tile_minmax, dim3((uint32_t)(mt.size() * instants)), dim3(256), 0, 0, d_mt.as<MinMaxTile>(), instants, buf.dtype,
+                           (uint32_t)buf.fractional_bits, (uint32_t)buf.round, d_out.as<int64_t>(), d_st.as<int32_t>());
+        K2R_HIP(hipGetLastError());
+        std::vector<int64_t> got(mt.size() * instants * 2ull);
+        K2R_HIP(hipMemcpy(got.data(), d_out.p, got.size() * 8, hipMemcpyDeviceToHost));
+        int32_t st = 0;
+        K2R_HIP(hipMemcpy(&st, d_st.p, 4, hipMemcpyDeviceToHost));
+        if (st != 0) return map_status(st);  // to_fixed panics (fixed.rs:39-70)
+        for (size_t q = 0; q < mt.size(); q++)
+            std::memcpy(&mm[2ull * mt_tile[q] * instants], &got[2ull * q * instants], 16ull * instants);
+    }
+    // ---- elision, sub-builds (superchunk.rs:144-181) ----
+    std::vector<char> elided(n_tiles, 1);
+    struct Sub {
+        size_t tile;
+        bool chunk;
+        std::string obj;
+        uint64_t size;
+        uint32_t snapshots, logs;
+    };
+    std::vector<Sub> subs;
+    std::vector<dcdf_tile_desc> chunk_descs;
+    std::vector<size_t> chunk_sub;
+    for (size_t i = 0; i < n_tiles; i++) {
+        if (!inside[i]) continue;
+        bool can_elide = true;
+        for (uint32_t t = 0; t < instants && can_elide; t++) can_elide = mm[2ull * (i * instants + t)] == mm[2ull * (i * instants + t) + 1];
+        if (can_elide) continue;
+        elided[i] = 0;
+        dcdf_tile_desc t = tiles[i];
+        bool build_subchunk = at_bottom;
+        if (!at_bottom) build_subchunk = levels_needed(std::max(t.rows, t.cols), k) <= sublevels[0];  // superchunk.rs:155-165
+        if (t.dtype == DCDF_F32 || t.dtype == DCDF_F64) {  // sub_buffer.compute_fractional_bits() (mmbuffer.rs:596-613)
+            int32_t rnd = 0, bits = 0;
+            const int rc = dcdf_suggest_fraction(&t, DCDF_MEM_DEVICE, &rnd, &bits);
+            if (rc != DCDF_OK) return rc;
+            if (t.round) bits = std::min<int32_t>(bits, t.fractional_bits);
+            else if (rnd) return DCDF_ERR_PRECISION;  // panic!("loss of precision")
+            t.fractional_bits = (uint8_t)bits;
+        }
+        Sub s{};
+        s.tile = i;
+        s.chunk = build_subchunk;
+        if (build_subchunk) {
+            chunk_descs.push_back(t);
+            chunk_sub.push_back(subs.size());
+        } else {
+            Level sub;
+            const int rc = build_level(cx, t, sublevels, n_sub, &sub);
+            if (rc != DCDF_OK) return rc;
+            s.obj = sub.node;
+            s.size = sub.size_self + 1;  // MMStruct3::size (mmstruct.rs:187-197)
+            s.snapshots = sub.snapshots;
+            s.logs = sub.logs;
+        }
+        subs.push_back(std::move(s));
+    }
+    if (!chunk_descs.empty()) {  // every Chunk::build of this level in one launch (superchunk.rs:169)
+        dcdf_encoded* enc = nullptr;
+        const int rc = dcdf_chunk_build_batch(chunk_descs.data(), chunk_descs.size(), k, DCDF_MEM_DEVICE, &enc);
+        if (rc != DCDF_OK) return rc;
+        int bad = DCDF_OK;
+        for (size_t q = 0; q < chunk_descs.size(); q++) {
+            if (enc[q].status != DCDF_OK) {
+                bad = enc[q].status;
+                break;
+            }
+            Sub& s = subs[chunk_sub[q]];
+            s.obj = header(2);      // NODE_MMSTRUCT3
+            s.obj.push_back(4);     // NODE_SUBCHUNK (mmstruct.rs:215-218)
+            s.obj.append((const char*)enc[q].bytes, enc[q].len);
+            s.size = enc[q].len + 1;
+            s.snapshots = enc[q].snapshots;
+            s.logs = enc[q].logs;
+        }
+        dcdf_free_encoded(enc, chunk_descs.size());
+        if (bad != DCDF_OK) return bad;
+    }
+    // ---- instant-major min / max (superchunk.rs:190-198) ----
+    std::vector<int64_t> mins(n_tiles * (size_t)instants), maxs(n_tiles * (size_t)instants);
+    for (uint32_t t = 0; t < instants; t++)
+        for (size_t i = 0; i < n_tiles; i++) {
+            mins[(size_t)t * n_tiles + i] = mm[2ull * (i * instants + t)];
+            maxs[(size_t)t * n_tiles + i] = mm[2ull * (i * instants + t) + 1];
+        }
+    // ---- references with de-duplication (superchunk.rs:199-236) ----
+    std::vector<const std::string*> to_hash;
+    for (const Sub& s : subs) to_hash.push_back(&s.obj);
+    std::vector<std::string> cids;
+    int rc = hash_objects(to_hash, cids);
+    if (rc != DCDF_OK) return rc;
+    std::vector<std::string> external;
+    std::map<std::string, uint32_t> ext_index;
+    std::vector<int64_t> refs(n_tiles, -1);
+    uint64_t sizes = 0;
+    out->elided = 0; out->snapshots = 0; out->logs = 0;
+    size_t si = 0;
+    for (size_t i = 0; i < n_tiles; i++) {
+        if (elided[i]) {
+            out->elided++;
+            continue;
+        }
+        const Sub& s = subs[si];
+        const std::string& cid = cids[si];
+        si++;
+        sizes += s.size;
+        save(cx, cid, s.obj);
+        auto it = ext_index.find(cid);
+        uint32_t index;
+        if (it == ext_index.end()) {
+            index = (uint32_t)external.size();
+            external.push_back(cid);
+            ext_index[cid] = index;
+        } else {
+            index = it->second;
+        }
+        refs[i] = index;
+        out->snapshots += s.snapshots;
+        out->logs += s.logs;
+    }
+    std::string links = header(1);  // NODE_LINKS (links.rs:65-76)
+    put_u32(links, (uint32_t)external.size());
+    for (const std::string& c : external) links += c;
+    const uint64_t size_external = 7 + 4 + 36ull * external.size();
+    std::vector<std::string> lcid;
+    rc = hash_objects({&links}, lcid);
+    if (rc != DCDF_OK) return rc;
+    save(cx, lcid[0], links);
+    // ---- the node (superchunk.rs:672-706) ----
+    std::string body;
+    put_u32(body, instants);
+    put_u32(body, rows);
+    put_u32(body, cols);
+    put_u32(body, (uint32_t)sidelen);
+    body.push_back((char)levels[0]);
+    put_u32(body, (uint32_t)chunks_sidelen);
+    put_u32(body, (uint32_t)subsidelen);
+    body.push_back((char)((buf.dtype == DCDF_F32 || buf.dtype == DCDF_F64) ? buf.fractional_bits : 0));
+    body.push_back((char)buf.dtype);
+    put_u32(body, (uint32_t)n_tiles);
+    for (size_t i = 0; i < n_tiles; i++) {  // Reference::write_to (superchunk.rs:843-861)
+        if (refs[i] < 0) body.push_back(0);
+        else {
+            body.push_back(2);
+            put_u32(body, (uint32_t)refs[i]);
+        }
+    }
+    body += lcid[0];
+    put_u32(body, 0);  // n_local
+    std::string dmax, dmin;
+    rc = dac_bytes(maxs, dmax);
+    if (rc != DCDF_OK) return rc;
+    rc = dac_bytes(mins, dmin);
+    if (rc != DCDF_OK) return rc;
+    body += dmax;
+    body += dmin;
+    out->node = header(2);
+    out->node.push_back(5);  // NODE_SUPERCHUNK
+    out->node += body;
+    out->size_self = 7 + body.size();  // superchunk.rs:652-670
+    out->size = out->size_self + size_external + sizes;
+    out->external = (uint32_t)external.size();
+    return DCDF_OK;
+}
+
+}  // namespace
+
+extern "C" void dcdf_free_superchunk(dcdf_superchunk* s) {
+    if (!s) return;
+    for (size_t i = 0; i < s->n_objects; i++) std::free(s->objects[i].bytes);
+    std::free(s->objects);
+    std::free(s);
+}
+
+extern "C" int dcdf_superchunk_build(const dcdf_tile_desc* buffer, const uint32_t* levels, size_t n_levels, int k, int mem,
+                                     dcdf_superchunk** out) {
+    if (!buffer || !levels || !out || n_levels < 2 || k < 2 || k > 16 || (mem != DCDF_MEM_HOST && mem != DCDF_MEM_DEVICE)) return DCDF_ERR_BAD_ARG;
+    if (!buffer->base || buffer->instants == 0 || buffer->rows == 0 || buffer->cols == 0) return DCDF_ERR_BAD_ARG;
+    if (buffer->dtype != DCDF_I32 && buffer->dtype != DCDF_I64 && buffer->dtype != DCDF_F32 && buffer->dtype != DCDF_F64) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    dcdf_tile_desc dev = *buffer;
+    DevBuf stage;
+    if (mem == DCDF_MEM_HOST) {  // dense copy of the whole view in HBM; every tile below is a strided view of it
+        const size_t es = esize(buffer->dtype);
+        const size_t n = (size_t)buffer->instants * buffer->rows * buffer->cols;
+        std::vector<uint8_t> dense(n * es);
+        uint8_t* d = dense.data();
+        for (uint32_t t = 0; t < buffer->instants; t++)
+            for (uint32_t r = 0; r < buffer->rows; r++)
+                for (uint32_t c = 0; c < buffer->cols; c++, d += es)
+                    std::memcpy(d, (const uint8_t*)buffer->base + ((int64_t)t * buffer->stride_t + (int64_t)r * buffer->stride_r + (int64_t)c * buffer->stride_c) * (int64_t)es, es);
+        K2R_HIP(stage.alloc(dense.size()));
+        K2R_HIP(hipMemcpy(stage.p, dense.data(), dense.size(), hipMemcpyHostToDevice));
+        dev.base = stage.p;
+        dev.stride_c = 1;
+        dev.stride_r = buffer->cols;
+        dev.stride_t = (int64_t)buffer->rows * buffer->cols;
+    }
+    Ctx cx;
+    cx.k = k;
+    Level top;
+    const int rc = build_level(cx, dev, levels, n_levels, &top);
+    if (rc != DCDF_OK) return rc;
+    std::vector<std::string> tcid;
+    const int rc2 = hash_objects({&top.node}, tcid);
+    if (rc2 != DCDF_OK) return rc2;
+    dcdf_superchunk* s = (dcdf_superchunk*)std::calloc(1, sizeof(dcdf_superchunk));
+    if (!s) return DCDF_ERR_NOMEM;
+    s->n_objects = cx.objects.size() + 1;
+    s->objects = (dcdf_stored_object*)std::calloc(s->n_objects, sizeof(dcdf_stored_object));
+    if (!s->objects) {
+        std::free(s);
+        return DCDF_ERR_NOMEM;
+    }
+    for (size_t i = 0; i < s->n_objects; i++) {
+        const std::string& o = i + 1 < s->n_objects ? cx.objects[i] : top.node;
+        const std::string& c = i + 1 < s->n_objects ? cx.cids[i] : tcid[0];
+        s->objects[i].bytes = (uint8_t*)std::malloc(o.size() ? o.size() : 1);
+        if (!s->objects[i].bytes) {
+            dcdf_free_superchunk(s);
+            return DCDF_ERR_NOMEM;
+        }
+        std::memcpy(s->objects[i].bytes, o.data(), o.size());
+        s->objects[i].len = o.size();
+        std::memcpy(s->objects[i].cid, c.data(), 36);
+    }
+    s->size = top.size;
+    s->elided = top.elided;
+    s->local = 0;
+    s->external = top.external;
+    s->snapshots = top.snapshots;
+    s->logs = top.logs;
+    *out = s;
+    return DCDF_OK;
+}

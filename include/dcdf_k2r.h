@@ -115,6 +115,36 @@ int dcdf_encoder_gather(dcdf_encoder* enc, uint8_t* dst, size_t cap, uint64_t* o
 int dcdf_encoder_object_sha256(dcdf_encoder* enc, uint8_t* digests, float* kernel_ms);
 void dcdf_encoder_destroy(dcdf_encoder* enc);
 
+/* ---- superchunk assembly (the caller of Chunk::build) ---------------------------------------- */
+
+/* One object the reference would hand to `resolver.save` (resolver.rs:126-138): the 7-byte header (u16 0xDCE0, u32 1,
+ * u8 node type) + the node, and its CID as MemoryMapper names it (testing.rs:172-183: CIDv1, codec 0x12, sha2-256). */
+typedef struct dcdf_stored_object {
+    uint8_t cid[36];
+    uint8_t* bytes;
+    size_t len;
+} dcdf_stored_object;
+
+/* `MMStruct3Build` of a Superchunk (mmstruct.rs:24-34) plus the objects to store: framed sub-chunks (mmstruct.rs:215-218),
+ * nested Superchunk nodes, `Links` nodes (links.rs:65-76), de-duplicated by CID like `external_references`
+ * (superchunk.rs:199-235), in save order; the LAST object is the Superchunk node itself (superchunk.rs:672-706), which
+ * `Superchunk::build` leaves to its caller to save. */
+typedef struct dcdf_superchunk {
+    dcdf_stored_object* objects;
+    size_t n_objects;
+    uint64_t size;
+    uint32_t elided, local, external, snapshots, logs;
+} dcdf_superchunk;
+
+/* Replaces `Superchunk::build(resolver, buffer, shape, levels, k)` (superchunk.rs:88-270): uniform-tile elision from
+ * per-tile per-instant (min,max) computed on the device (mmbuffer.rs:366-499), per-tile fractional bits
+ * (superchunk.rs:167), one batched Chunk::build launch per level, nested superchunks, the reference table, the
+ * instant-major min / max Dacs, Links, object framing and CIDs.  `buffer` = the whole [instants, rows, cols] view
+ * (fractional_bits / round as the caller's MMBuffer3 carries them); sum(levels) must equal ceil(log_k(max(rows, cols))). */
+int dcdf_superchunk_build(const dcdf_tile_desc* buffer, const uint32_t* levels, size_t n_levels, int k, int mem,
+                          dcdf_superchunk** out);
+void dcdf_free_superchunk(dcdf_superchunk* s);
+
 /* ---- query --------------------------------------------------------------------------------- */
 
 typedef struct dcdf_chunk dcdf_chunk; /* an opened, device-resident encoded chunk */

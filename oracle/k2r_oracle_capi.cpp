@@ -396,6 +396,20 @@ int orc_dac_dump(const int64_t* values, size_t nvalues, int64_t** out, size_t* n
     ORC_CATCH
 }
 
+// Dac::from + Dac::write_to (dac.rs:37-44,101-131): the serialized bytes
+int orc_dac_serialize(const int64_t* values, size_t nvalues, uint8_t** out_bytes, size_t* out_len) {
+    ORC_TRY
+    Dac d = Dac::from(std::vector<int64_t>(values, values + nvalues));
+    Writer w;
+    d.write_to(w);
+    uint8_t* p = (uint8_t*)std::malloc(w.buf.size() ? w.buf.size() : 1);
+    std::memcpy(p, w.buf.data(), w.buf.size());
+    *out_bytes = p;
+    *out_len = w.buf.size();
+    return 0;
+    ORC_CATCH
+}
+
 int orc_to_fixed_f32(float v, int bits, int round, int64_t* out) {
     ORC_TRY
     *out = to_fixed<float>(v, (size_t)bits, round != 0);

@@ -259,6 +259,17 @@ def dac_dump(values):
     return {"levels": levels, "collect": c.vec(), "size": c.one(), "serialized_len": c.one(), "collect_reread": c.vec()}
 
 
+def dac_serialize(values):
+    """Dac::from(values) serialized (dac.rs:37-44)."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    _check(lib().orc_dac_serialize(C.c_void_p(v.ctypes.data), C.c_size_t(len(v)), C.byref(out), C.byref(n)))
+    data = C.string_at(out, n.value)
+    lib().orc_free(out)
+    return data
+
+
 def to_fixed(v, bits, round_, ftype="f64"):
     out = C.c_int64()
     if ftype == "f32":
