@@ -6,10 +6,11 @@ set -o pipefail
 TAG=${1:-rXX}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
-mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/sq
+mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/sq $OUT/sq2
 B="python3 bench.py --cpu-sample 0 --verify 1 --no-gather ${BENCH_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B > $OUT/write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq -- $B > $OUT/sq.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/sq2 -- $B > $OUT/sq2.log 2>&1 || exit 1
 python3 tools/pmc_summary.py $OUT $TAG

@@ -26,7 +26,7 @@ for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     stats = open(f).read()
     open(out + "/%s_kernel_stats.csv" % tag, "w").write(stats)
 res = {"tag": tag}
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     c = counters(sub)
     if c:
         res[sub] = {k: v for k, v in c[0].items()}
