@@ -189,6 +189,7 @@ K2R_HD void snapshot_search(const uint8_t* b, const InstDesc& S, uint32_t top, u
     int sp = 0;
     auto enter = [&](uint32_t sidelen, uint32_t t, uint32_t bo, uint32_t l, uint32_t r, uint32_t index, int64_t mn,
                      int64_t mx, uint32_t toff, uint32_t loff) {
+        if (sidelen / k == 0) return;  // (malformed input only: dcdf_chunk_open rejects a sidelen that is no power of k)
         SFrame& f = st[sp++];
         f.sl = sidelen / k;
         f.base_s = 1 + bmd_rank(b, S.T, index) * k * k;

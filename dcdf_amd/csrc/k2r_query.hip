@@ -412,6 +412,46 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
         }
     }
     if (!cur.ok || c->descs.empty() || cur.pos != len) return DCDF_ERR_FORMAT;
+    // Structural validation (chunks arrive by CID from an untrusted store; the reference would panic on a malformed one, the
+    // GPU must not chase out-of-range indices): every count the decoders rely on is checked against the bitmaps' popcounts.
+    {
+        bool index_ok = true;
+        auto ones = [&](const BmDesc& d) -> uint64_t {  // popcount of the bitmap; checks its rank index on the way (bitmap.rs:97-104)
+            uint64_t n = 0;
+            for (uint32_t w = 0; w < (d.len + 31) / 32; w++) {
+                uint32_t x = load_be32(bytes + d.words_off + 4 * w);
+                const uint32_t left = d.len - 32 * w;
+                if (left < 32) x &= ~(0xffffffffu >> left);  // padding bits do not count
+                n += (uint64_t)__builtin_popcount(x);
+                if (d.k == 4 && (w & 3) == 3 && (w >> 2) < d.len / 128 && load_be32(bytes + d.idx_off + 4 * (w >> 2)) != (uint32_t)n) index_ok = false;
+            }
+            return n;
+        };
+        auto dac_ok = [&](const DacDesc& d, uint64_t expect_len) -> bool {
+            if (expect_len == 0) return d.nlev == 0;
+            if (d.nlev == 0 || d.bm[0].len != expect_len) return false;
+            for (uint32_t l = 0; l < d.nlev; l++) {
+                if (d.bm[l].k != 4) return false;
+                const uint64_t next = ones(d.bm[l]);
+                if (l + 1 < d.nlev ? d.bm[l + 1].len != next : next != 0) return false;  // dac.rs:83-90: every hop lands in the next plane
+            }
+            return true;
+        };
+        for (const InstDesc& d : c->descs) {
+            if (d.k < 2 || d.k > 255 || d.rows == 0 || d.cols == 0) return DCDF_ERR_FORMAT;
+            uint64_t side = 1;  // snapshot.rs:118-119: the smallest power of k covering the tile
+            while (side < std::max(d.rows, d.cols)) side *= d.k;
+            if (d.sidelen != side) return DCDF_ERR_FORMAT;
+            if (d.T.k != 4 || (d.is_log && d.E.k != 4)) return DCDF_ERR_FORMAT;  // bitmap.rs:69,130
+            const uint64_t internal = ones(d.T);
+            const uint64_t visited = 1 + (uint64_t)d.k * d.k * internal;          // snapshot.rs:177: four children per internal node
+            if (d.T.len > visited) return DCDF_ERR_FORMAT;
+            if (!dac_ok(d.mx, visited) || !dac_ok(d.mn, internal)) return DCDF_ERR_FORMAT;
+            if (d.is_log && d.E.len != d.T.len - internal) return DCDF_ERR_FORMAT;  // one eqB bit per T = 0 (log.rs:137-144)
+            if (d.is_log) (void)ones(d.E);
+            if (!index_ok) return DCDF_ERR_FORMAT;
+        }
+    }
     c->instants = (uint32_t)c->descs.size();
     c->rows = c->descs[0].rows;  // chunk.rs:119-123
     c->cols = c->descs[0].cols;

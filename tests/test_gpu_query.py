@@ -223,3 +223,41 @@ def test_suggest_fraction_golden_and_random(dc):  # fixed.rs:96-159, tests fixed
         O.suggest_fraction(-np.ones((1, 2, 2), dtype=np.float32), "f32"))
     with pytest.raises(dc.DcdfError):
         dc.suggest_fraction(np.full((1, 1, 2), 1e300, dtype=np.float64))  # whole part needs more than 62 bits
+
+
+def test_malformed_chunks_are_rejected_at_open(dc):
+    """Chunks arrive by CID from an untrusted store: dcdf_chunk_open validates structure (sidelen a power of k, rank-index
+    stride 4, every Dac level's length == popcount of the level below, Lmax / Lmin / eqB lengths vs. popcount(T)) and returns
+    DCDF_ERR_FORMAT; a corrupted chunk never reaches the kernels."""
+    from dcdf_amd import synth
+    a = synth.cells(77, 0, 5, 0, 32, 0, 32, np.int32)
+    good = bytearray(dc.Chunk.build(a).data.write_to())
+    dc.Chunk(bytes(good)).close()  # sanity: the intact chunk opens
+    rng = np.random.default_rng(11)
+    rejected = opened = 0
+    cases = []
+    for cut in (5, 6, 7, 20, len(good) - 1, len(good) // 2):  # truncations
+        cases.append(bytes(good[:cut]))
+    t = bytearray(good); t[7] = 3; cases.append(bytes(t))          # k = 3 with sidelen 32: not a power of k
+    t = bytearray(good); t[16:20] = (64).to_bytes(4, "big"); cases.append(bytes(t))   # sidelen 64 for a 32 x 32 tile
+    t = bytearray(good); t[24:28] = (8).to_bytes(4, "big"); cases.append(bytes(t))    # T bitmap's rank-index stride
+    t = bytearray(good); t[20:24] = (len(good) * 8).to_bytes(4, "big"); cases.append(bytes(t))  # absurd T length
+    for _ in range(300):  # random byte flips anywhere
+        t = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            t[int(rng.integers(0, len(t)))] ^= int(rng.integers(1, 256))
+        cases.append(bytes(t))
+    for data in cases:
+        try:
+            c = dc.Chunk(data)
+        except dc.DcdfError as e:
+            assert e.code in (-7, -1), e.code
+            rejected += 1
+            continue
+        opened += 1  # a flip inside value bytes leaves a well-formed chunk: queries must run without faulting
+        shp = c.shape()
+        w = c.fill_window(dc.Cube(0, shp[0], 0, shp[1], 0, shp[2]), dtype=np.int64)
+        assert w.shape == tuple(shp)
+        c.iter_search(dc.Cube(0, shp[0], 0, shp[1], 0, shp[2]), -5, 5)
+        c.close()
+    assert rejected >= 10 and opened > 0
