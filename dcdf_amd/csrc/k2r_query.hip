@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -144,6 +145,18 @@ constexpr uint32_t WQ_NONE = 0xffffffffu;
 struct WaveQ {
     uint32_t it[WQ_CAP], is[WQ_CAP], org[WQ_CAP];  // first child of the node in the log / snapshot tree (or NONE), origin row << 16 | col
     int64_t mt[WQ_CAP], ms[WQ_CAP];                 // log.rs:360-361 max_t, max_s
+};
+struct GpuExecScan {  // inclusive prefix sum over the 64 lanes (DPP), as GpuExec::wave_incl_scan
+    __device__ __forceinline__ static uint32_t incl(uint32_t v) {
+        int x = (int)v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+        return (uint32_t)x;
+    }
 };
 struct NodeSt {
     uint32_t bt, bs;  // index of the node's FIRST CHILD in the log / snapshot tree (1 + rank(T, node) * k^2), or NONE
@@ -329,6 +342,291 @@ k_window_wave(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ i
     }
 }
 
+
+// ---- k = 2, node-wise: one lane per frontier NODE, its four children share their loads ---------------------------------
+// Siblings are adjacent in every stream (children of a node sit at base .. base + 3): their four T bits and ranks come from
+// ONE 16-byte load of the rank block (+ its index word), their four Lmax bytes from ONE 4-byte load, their continuation bits
+// from the same kind of block load, the second bytes of the long ones from one more 4-byte load.  ~14 loads per node for both
+// trees instead of ~18 per CHILD.
+struct Blk16 {
+    uint32_t w[4];
+} __attribute__((aligned(1)));
+// The chunk bytes are global memory, but a pointer loaded from a table is "generic" to the compiler and every access through
+// it a FLAT instruction (slower, and counted in both wait counters): the node-wise walk uses address-space-1 pointers.
+typedef const __attribute__((address_space(1))) uint8_t* gbytes;
+__device__ __forceinline__ uint32_t gld32(gbytes p) {  // unaligned 4-byte load, native order
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    return *(const __attribute__((address_space(1))) u32u*)p;
+}
+__device__ __forceinline__ uint32_t gld_be32(gbytes p) { return __builtin_bswap32(gld32(p)); }
+__device__ __forceinline__ bool gbm_get(gbytes b, const BmDesc& d, uint32_t i) {
+    const uint32_t w = i >> 5;
+    if (w >= (d.len + 31) / 32) return false;
+    return (gld_be32(b + d.words_off + 4 * w) >> (31 - (i & 31))) & 1u;
+}
+// rank1(T, i) and the four bits i .. i+3 (bit i = 8), bits at or beyond d.len read as 0.  Needs d.k == 4 and i < d.len.
+__device__ __forceinline__ uint32_t rank_nib(gbytes b, const BmDesc& d, uint32_t i, uint32_t* nib) {
+    const uint32_t w0 = i >> 5, blk = w0 >> 2, sh = i & 31u;
+    uint32_t cnt = blk ? gld_be32(b + d.idx_off + 4 * (blk - 1)) : 0u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+    const u32x4 raw = *(const __attribute__((address_space(1))) u32x4*)(b + d.words_off + 16 * blk);
+    const uint32_t w[4] = {__builtin_bswap32(raw.x), __builtin_bswap32(raw.y), __builtin_bswap32(raw.z), __builtin_bswap32(raw.w)};
+    const uint32_t q0 = w0 & 3u;
+    uint32_t x = w[0], nx = w[1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if ((uint32_t)q < q0) cnt += popc32(w[q]);
+        if ((uint32_t)q == q0) {
+            x = w[q];
+            nx = q < 3 ? w[q + 1] : 0u;
+        }
+    }
+    if (q0 == 3 && sh > 28) nx = gld_be32(b + d.words_off + 4 * (w0 + 1));  // the group of four straddles the block's end (3 in 128)
+    if (sh) cnt += popc32(x >> (32 - sh));
+    uint32_t n4 = (uint32_t)(((((uint64_t)x << 32) | nx) >> (60 - sh)) & 15u);
+    const uint32_t valid = d.len - i;  // > 0
+    if (valid < 4) n4 &= (0xfu << (4 - valid)) & 0xfu;
+    *nib = n4;
+    return cnt;
+}
+// What the node-wise walk needs of one tree, copied out of its InstDesc once per item (wave-uniform: lives in SGPRs instead
+// of being re-fetched through a pointer the compiler must assume the output stores alias).
+struct TreeRef {
+    BmDesc T, E, c0, c1;      // T, eqB, continuation bitmaps of the Lmax Dac's planes 0 and 1
+    uint32_t by0, by1, nlev;  // Lmax plane-0 / plane-1 bytes, number of planes
+};
+typedef const __attribute__((address_space(1))) InstDesc* gdesc;
+__device__ __forceinline__ BmDesc bm_copy(const __attribute__((address_space(1))) BmDesc* p) { return BmDesc{p->len, p->k, p->idx_off, p->words_off}; }
+__device__ __forceinline__ TreeRef tree_ref(gdesc p) {
+    TreeRef t;
+    t.T = bm_copy(&p->T); t.E = bm_copy(&p->E); t.c0 = bm_copy(&p->mx.bm[0]); t.c1 = bm_copy(&p->mx.bm[1]);
+    t.by0 = p->mx.bytes_off[0]; t.by1 = p->mx.bytes_off[1]; t.nlev = p->mx.nlev;
+    return t;
+}
+__device__ __forceinline__ TreeRef tree_ref(const InstDesc& d) {
+    TreeRef t;
+    t.T = d.T; t.E = d.E; t.c0 = d.mx.bm[0]; t.c1 = d.mx.bm[1];
+    t.by0 = d.mx.bytes_off[0]; t.by1 = d.mx.bytes_off[1]; t.nlev = d.mx.nlev;
+    return t;
+}
+// the four Lmax values at index i .. i+3 (those at or beyond the Dac's length: 0); `full` = the whole Dac, for values of
+// three or more bytes (rare)
+__device__ __forceinline__ void dac4(gbytes b, const TreeRef& t, const DacDesc& full, uint32_t i, int64_t (&out)[4]) {
+    const uint32_t len = t.c0.len;
+    const uint32_t b0 = gld32(b + t.by0 + i);
+    uint32_t cb = 0, r0 = 0;
+    if (t.nlev > 1) r0 = rank_nib(b, t.c0, i, &cb);
+    uint32_t cb1 = 0;
+    const uint32_t b1 = gld32(b + t.by1 + r0);  // (no branch: with a single plane by1 = r0 = 0, a harmless read of the chunk's first bytes)
+    if (t.nlev > 2 && cb) (void)rank_nib(b, t.c1, r0, &cb1);
+    uint32_t q = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint64_t n = (b0 >> (8 * c)) & 0xffu;
+        const bool more = (cb >> (3 - c)) & 1u;
+        if (more) {
+            if ((cb1 >> (3 - q)) & 1u) {  // three or more bytes: the general walk
+                out[c] = i + c < len ? dacd_get((const uint8_t*)b, full, i + c) : 0;
+                q++;
+                continue;
+            }
+            n |= (uint64_t)((b1 >> (8 * q)) & 0xffu) << 8;
+            q++;
+        }
+        out[c] = i + c < len ? (int64_t)((n >> 1) ^ (0 - (n & 1))) : 0;
+    }
+}
+struct Kids {
+    NodeSt st[4];
+    int64_t val[4];
+    uint32_t fill;  // bit c: child c's whole square has the single value val[c]
+};
+// the four children of node p (log.rs:392-505 / snapshot.rs:281-299 for all of i, j at once)
+__device__ __forceinline__ void expand4(gbytes b, const TreeRef& S, const DacDesc& Sfull, const TreeRef& L, const DacDesc& Lfull,
+                                        const NodeSt& p, Kids* o) {
+    const bool has_t = p.bt != WQ_NONE, has_s = p.bs != WQ_NONE;
+    int64_t vt[4] = {p.mt, p.mt, p.mt, p.mt}, vs[4] = {0, 0, 0, 0};
+    uint32_t tt = 0, ts = 0, rt = 0, rs = 0;  // T nibbles (bit c = 8 >> c) and rank of the first child
+    bool cells_t = true, cells_s = true;      // the children are beyond T: cells
+    if (has_t) {
+        dac4(b, L, Lfull, p.bt, vt);
+        cells_t = p.bt >= L.T.len;
+        if (!cells_t) rt = rank_nib(b, L.T, p.bt, &tt);
+    }
+    if (has_s) {
+        dac4(b, S, Sfull, p.bs, vs);
+        cells_s = p.bs >= S.T.len;
+        if (!cells_s) rs = rank_nib(b, S.T, p.bs, &ts);
+    }
+    o->fill = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const bool bit_t = (tt >> (3 - c)) & 1u, bit_s = (ts >> (3 - c)) & 1u;
+        const bool leaf_t = !has_t || cells_t || !bit_t, leaf_s = !has_s || cells_s || !bit_s;
+        const uint32_t rtc = rt + popc32(tt >> (4 - c)), rsc = rs + popc32(ts >> (4 - c));  // rank(T, base + c)
+        const int64_t mt_ = vt[c], ms_ = has_s ? p.ms - vs[c] : p.ms;
+        o->val[c] = mt_ + ms_;
+        NodeSt& n = o->st[c];
+        n.mt = mt_;
+        n.ms = ms_;
+        n.bt = WQ_NONE;
+        n.bs = WQ_NONE;
+        if (leaf_t && leaf_s) {
+            o->fill |= 1u << c;
+        } else if (leaf_s) {
+            n.bt = 1 + rtc * 4;
+        } else if (leaf_t) {
+            if (has_t && !cells_t && !gbm_get(b, L.E, p.bt + c - rtc)) o->fill |= 1u << c;  // uniform, not "equal" (log.rs:452-467)
+            else n.bs = 1 + rsc * 4;
+        } else {
+            n.bt = 1 + rtc * 4;
+            n.bs = 1 + rsc * 4;
+        }
+    }
+}
+
+// (k = 2, sub-windows on the 32-grid: one node per level down to side 32, then at most 4, 16, 64: 96 entries hold every level)
+constexpr int WQ2_CAP = 96;
+struct WaveQ2 {
+    uint32_t it[WQ2_CAP], is[WQ2_CAP], org[WQ2_CAP];
+    int64_t mt[WQ2_CAP], ms[WQ2_CAP];
+};
+// MW = waves per SIMD the register allocator must leave room for; DENSE64: the batched form's output (int64, unit column stride)
+template <int MW, bool DENSE64>
+__global__ void __launch_bounds__(256, MW)
+k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ items, uint32_t n_items, void* out, int32_t out_dtype) {
+    __shared__ WaveQ2 wq[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveQ2& q = wq[wave];
+    for (uint32_t item = blockIdx.x * 4u + (uint32_t)wave; item < n_items; item += gridDim.x * 4u) {
+        const WinItem I = items[item];
+        const ChunkRef C = chunks[I.chunk];
+        const uint8_t* const b = C.bytes;
+        const gbytes gb = (gbytes)C.bytes;
+        const gdesc gD = (gdesc)C.descs + I.inst;
+        const bool has_log = gD->is_log != 0;
+        const gdesc gS = has_log ? (gdesc)C.descs + gD->snap : gD;
+        const InstDesc& D = C.descs[I.inst];                       // (generic views: only for the rare general Dac walk)
+        const InstDesc& SD = has_log ? C.descs[gD->snap] : D;
+        const TreeRef S = tree_ref(gS), L = tree_ref(gD);          // (L is only looked at when has_log)
+        const uint32_t sidelen0 = gD->sidelen;
+        const uint32_t wtop = I.top, wbot = I.bottom, wleft = I.left, wright = I.right, osr = I.out_sr;
+        const int64_t obase = (int64_t)I.out_off - (int64_t)wtop * osr - (int64_t)wleft;  // element offset of chunk cell (0, 0)
+        auto put = [&](uint32_t r, uint32_t c, int64_t v) {
+            const int64_t off = obase + (int64_t)(r * osr + c);
+            if (DENSE64) ((int64_t*)out)[off] = v;
+            else store_typed(out, off, out_dtype, v, C.fbits);
+        };
+        auto fill_wave = [&](uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int64_t v) {
+            const uint32_t w = c1 - c0, area = (r1 - r0) * w;      // w <= 32, area <= 1024
+            const uint32_t inv = (65536u + w - 1) / w;             // i / w == (i * inv) >> 16 for i < 2048
+            for (uint32_t i = (uint32_t)lane; i < area; i += 64) {
+                const uint32_t rr = (i * inv) >> 16;
+                put(r0 + rr, c0 + i - rr * w, v);
+            }
+        };
+        const bool single_s = !gbm_get(gb, S.T, 0);
+        const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
+        const int64_t max_s0 = dacd_get(b, SD.mx, 0), max_t0 = has_log ? dacd_get(b, D.mx, 0) : 0;
+        const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
+        if (all_one) {
+            fill_wave(wtop, wbot, wleft, wright, max_t0 + max_s0);
+            continue;
+        }
+        if (lane == 0) {
+            q.it[0] = (has_log && !single_t) ? 1u : WQ_NONE;
+            q.is[0] = single_s ? WQ_NONE : 1u;
+            q.org[0] = 0;
+            q.mt[0] = max_t0;
+            q.ms[0] = max_s0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t lo = 0, hi = 1, side = sidelen0;
+        while (side > 4) {  // lane = frontier node; children of side >= 4 go to the next frontier
+            const uint32_t cs = side >> 1;
+            uint32_t next = hi;
+            for (uint32_t base = lo; base < hi; base += 64) {
+                const uint32_t n = base + (uint32_t)lane;
+                const bool live = n < hi;
+                Kids kd;
+                kd.fill = 0;
+                uint32_t po = 0, inter = 0;  // children meeting the sub-window
+                if (live) {
+                    const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+                    po = q.org[n];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t cr = (po >> 16) + (uint32_t)(c >> 1) * cs, cc = (po & 0xffffu) + (uint32_t)(c & 1) * cs;
+                        if (cr < wbot && cr + cs > wtop && cc < wright && cc + cs > wleft) inter |= 1u << c;
+                    }
+                    if (inter) expand4(gb, S, SD.mx, L, D.mx, p, &kd);
+                }
+                const uint32_t pushm = inter & ~kd.fill, fillm = inter & kd.fill;
+                const uint32_t np = popc32(pushm);
+                const uint32_t inc = GpuExecScan::incl(np);
+                uint32_t pos = next + inc - np;
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if ((pushm >> c) & 1u) {
+                        if (pos < (uint32_t)WQ2_CAP) {
+                            const uint32_t cr = (po >> 16) + (uint32_t)(c >> 1) * cs, cc = (po & 0xffffu) + (uint32_t)(c & 1) * cs;
+                            q.it[pos] = kd.st[c].bt; q.is[pos] = kd.st[c].bs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = kd.st[c].mt; q.ms[pos] = kd.st[c].ms;
+                        }
+                        pos++;
+                    }
+                next += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {  // uniform / not-"equal" children: their part of the sub-window, by the whole wave
+                    unsigned long long bf = __builtin_amdgcn_ballot_w64((fillm >> c) & 1u);
+                    const uint32_t cr = (po >> 16) + (uint32_t)(c >> 1) * cs, cc = (po & 0xffffu) + (uint32_t)(c & 1) * cs;
+                    while (bf) {
+                        const int l = __builtin_ctzll(bf);
+                        bf &= bf - 1;
+                        const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)cr, l), ccl = (uint32_t)__builtin_amdgcn_readlane((int)cc, l);
+                        const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kd.val[c], l);
+                        const uint32_t vhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)kd.val[c] >> 32), l);
+                        fill_wave(rr > wtop ? rr : wtop, rr + cs < wbot ? rr + cs : wbot, ccl > wleft ? ccl : wleft, ccl + cs < wright ? ccl + cs : wright,
+                                  (int64_t)(((uint64_t)vhi << 32) | vlo));
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            lo = hi;
+            hi = next < (uint32_t)WQ2_CAP ? next : (uint32_t)WQ2_CAP;
+            side = cs;
+        }
+        // ---- nodes of side 4: the lane finishes its 16 cells ----
+        for (uint32_t base = lo; base < hi; base += 64) {
+            const uint32_t n = base + (uint32_t)lane;
+            if (n >= hi) continue;
+            const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+            const uint32_t po = q.org[n], pr = po >> 16, pc = po & 0xffffu;
+            Kids kd;
+            expand4(gb, S, SD.mx, L, D.mx, p, &kd);
+            const bool inside = pr >= wtop && pr + 4 <= wbot && pc >= wleft && pc + 4 <= wright;  // no clipping needed
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t cr = pr + 2u * (uint32_t)(c >> 1), cc = pc + 2u * (uint32_t)(c & 1);
+                if (!inside && !(cr < wbot && cr + 2 > wtop && cc < wright && cc + 2 > wleft)) continue;
+                int64_t v[4] = {kd.val[c], kd.val[c], kd.val[c], kd.val[c]};
+                if (!((kd.fill >> c) & 1u)) {
+                    Kids g;
+                    expand4(gb, S, SD.mx, L, D.mx, kd.st[c], &g);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = g.val[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t r = cr + (uint32_t)(e >> 1), cl = cc + (uint32_t)(e & 1);
+                    if (inside || (r >= wtop && r < wbot && cl >= wleft && cl < wright)) put(r, cl, v[e]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // get / fill_cell: one thread per (query) point
 struct PointQuery {
     uint32_t chunk, instant, row, col;
@@ -460,7 +758,7 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
             d.sidelen < std::max(d.rows, d.cols))
             return DCDF_ERR_FORMAT;
     c->len = len;
-    K2R_HIP(c->d_bytes.alloc(len + 8));
+    K2R_HIP(c->d_bytes.alloc(len + 64));  // (slack: the wave decoder reads whole 16-byte blocks / 4-byte groups at the tail)
     K2R_HIP(hipMemcpy(c->d_bytes.p, bytes, len, hipMemcpyHostToDevice));
     K2R_HIP(c->d_descs.alloc(c->descs.size() * sizeof(InstDesc)));
     K2R_HIP(hipMemcpy(c->d_descs.p, c->descs.data(), c->descs.size() * sizeof(InstDesc), hipMemcpyHostToDevice));
@@ -555,14 +853,20 @@ static bool wave_kernel_ok(const dcdf_chunk* h) {
     const uint32_t k = h->descs[0].k;
     return k * k <= 64 && h->descs[0].sidelen <= 65535;
 }
-static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>& items, void* d_out, int32_t dtype, hipEvent_t e0, hipEvent_t e1) {
+static bool node_kernel_ok(const dcdf_chunk* h) { return h->descs[0].k == 2 && h->descs[0].sidelen >= 4; }
+static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>& items, void* d_out, int32_t dtype, hipEvent_t e0, hipEvent_t e1,
+                               bool node_wise) {
     DevBuf d_items;
     K2R_HIP(d_items.alloc(items.size() * sizeof(WinItem)));
     K2R_HIP(hipMemcpy(d_items.p, items.data(), items.size() * sizeof(WinItem), hipMemcpyHostToDevice));
     const uint32_t n = (uint32_t)items.size();
     const uint32_t grid = std::min<uint32_t>((n + 3) / 4, 256u * 16u);
     if (e0) K2R_HIP(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_window_wave, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+    if (node_wise) {
+        if (dtype == DCDF_I64) hipLaunchKernelGGL((k_window_wave2<4, true>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+        else hipLaunchKernelGGL((k_window_wave2<4, false>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+    }
+    else hipLaunchKernelGGL(k_window_wave, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
     if (e1) K2R_HIP(hipEventRecord(e1, 0));
     K2R_HIP(hipGetLastError());
     K2R_HIP(hipDeviceSynchronize());
@@ -593,7 +897,7 @@ extern "C" int dcdf_chunk_fill_window(const dcdf_chunk* h, const dcdf_cube* cube
     if (wave_kernel_ok(h)) {
         std::vector<WinItem> items;
         window_items(0, c, 0, items);
-        const int rc = launch_window_items(d_ref, items, d_o.p, out_dtype, nullptr, nullptr);
+        const int rc = launch_window_items(d_ref, items, d_o.p, out_dtype, nullptr, nullptr, node_kernel_ok(h));
         if (rc != DCDF_OK) return rc;
     } else {
         hipLaunchKernelGGL(k_fill_window, dim3(1), dim3(256), 0, 0, d_ref.as<ChunkRef>(), d_q.as<WinQuery>(), 1u, d_o.p,
@@ -781,15 +1085,18 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
     K2R_HIP(d_o.alloc(total * 8));
     EventPair ev;
     K2R_HIP(ev.create());
-    bool all_wave = true;
-    for (const dcdf_chunk* u : uniq) all_wave = all_wave && wave_kernel_ok(u);
+    bool all_wave = true, all_node = true;
+    for (const dcdf_chunk* u : uniq) {
+        all_wave = all_wave && wave_kernel_ok(u);
+        all_node = all_node && node_kernel_ok(u);
+    }
     if (all_wave) {
         std::vector<WinItem> items;
         for (size_t q = 0; q < nq; q++) {
             const dcdf_cube c{qs[q].start, qs[q].end, qs[q].top, qs[q].bottom, qs[q].left, qs[q].right};
             window_items(qs[q].chunk, c, qs[q].out_off, items);
         }
-        rc = launch_window_items(d_refs, items, d_o.p, (int32_t)DCDF_I64, ev.e0, ev.e1);
+        rc = launch_window_items(d_refs, items, d_o.p, (int32_t)DCDF_I64, ev.e0, ev.e1, all_node);
         if (rc != DCDF_OK) return rc;
     } else {
         const uint32_t grid = (uint32_t)std::min<size_t>(nq, 1u << 20);
