@@ -105,7 +105,7 @@ static int validate_tile(const dcdf_tile_desc& t, int k, EncClass* cls, uint32_t
     if ((t.dtype == DCDF_F32 || t.dtype == DCDF_F64) && t.fractional_bits > 62) return DCDF_ERR_BAD_ARG;
     if (k < 2 || k > 16) return DCDF_ERR_BAD_ARG;
     const uint32_t lg = sidelen_log2(t.rows, t.cols);
-    if (k != 2 || lg < 3 || lg > 8) {  // outside the fused kernel: any k, sidelen 1 .. 1024
+    if (k != 2 || lg < 4 || lg > 8) {  // outside the fused kernel (k = 2, sidelen 16 .. 256): any k, sidelen 1 .. 1024
         uint64_t side;
         const uint32_t H = depth_for(t.rows, t.cols, (uint32_t)k, &side);
         if (side > kGenericMaxSidelen) return DCDF_ERR_UNSUPPORTED;

@@ -319,18 +319,11 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
     }
 }
 
-// Experimental level-order streaming log path (k2r_fastlog.h).  Bit-exact (tests/test_sim_fastlog.py, and on the card), but
-// measured SLOWER than the general path on MI355X: it trades barriers and record decoding for more
-// instructions per cell, and the kernel is bound by instruction issue, not by barriers.  Off unless built with -DK2R_FASTLOG=1.
-#ifndef K2R_FASTLOG
-#define K2R_FASTLOG 0
-#endif
 // The compact copy of a block's snapshot instant (see encode_chunk): 16 cells of sub-block j of thread tid, uint16
-// offsets from `base`.  General path: words [(j * NT + tid) * 8, +8) (a wave reads 2 KB contiguous per sub-block); with the
-// fast log path compiled in: [(tid * 4 + j) * 8, +8), the Morton order of the height-2 nodes that path walks.
+// offsets from `base`: words [(j * NT + tid) * 8, +8) (a wave reads 2 KB contiguous per sub-block).
 template <class C>
 K2R_HD uint32_t compact_slot(int tid, int j) {
-    return K2R_FASTLOG ? (uint32_t)tid * 4u + (uint32_t)j : (uint32_t)j * (uint32_t)C::NT + (uint32_t)tid;
+    return (uint32_t)j * (uint32_t)C::NT + (uint32_t)tid;
 }
 template <class C>
 K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int32_t (&dst)[16]) {
@@ -542,8 +535,6 @@ struct InstPlan {
     uint32_t lngV[3], lngM[3];  // log: index (among second bytes) of the first one of heights 0..2
 };
 
-template <class C, int STAGE_WORDS>
-struct FastShared;
 template <class C>
 struct EncPool {
     // One pool of LDS words with three lives per instant (general path):
@@ -558,11 +549,6 @@ struct EncPool {
     static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
     static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
     static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? 4900 : 0);  // sidelen 256: LDS filled to 160 KB
-    static constexpr int GENERAL_WORDS = 6 * C::NTOP + POOLW;   // tmin .. eq + pool: what the fast log path may alias
-    // staging words of the fast log path (k2r_fastlog.h): at sidelen 256 whatever the aliased area leaves after its tables,
-    // below that LDS is plentiful: 2 bytes per cell
-    static constexpr int FAST_FIXED = 2 * C::NW * 44 + C::NW * 4 * 14 + C::NW * 20 + 24 + 25 * C::NW + 64;
-    static constexpr int STAGE_WORDS = C::NT < 64 ? 2 : (C::H == 8 ? ((GENERAL_WORDS - FAST_FIXED) & ~1) : (1 << (2 * C::H - 1)));
 };
 
 template <class C>
@@ -571,17 +557,9 @@ struct EncShared : EncPool<C> {
     using EncPool<C>::POOL_BMV1;
     using EncPool<C>::POOL_PREFV;
     using EncPool<C>::POOLW;
-    union {
-        struct {  // the general path (this file)
-            int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
-            uint32_t eq[C::NTOP];
-            uint32_t pool[EncPool<C>::POOLW];
-        };
-#if K2R_FASTLOG
-        FastShared<C, EncPool<C>::STAGE_WORDS> fast;  // the fast log path (k2r_fastlog.h); the two alternate per instant
-#endif
-    };
-    uint32_t f_top, f_flags;  // fast path: staging pool allocation pointer (8-byte units), failure flags
+    int32_t tmin[C::NTOP], tmax[C::NTOP], smin[C::NTOP], smax[C::NTOP], diff[C::NTOP];
+    uint32_t eq[C::NTOP];
+    uint32_t pool[EncPool<C>::POOLW];
     uint32_t bmT[C::WT + 1], bmE[C::WT + 1];
     uint32_t bmV0[C::WV + 1];
     uint32_t bmM[2][C::WT + 1];
@@ -905,11 +883,6 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
     }
 }
 
-}  // namespace k2r
-#if K2R_FASTLOG
-#include "k2r_fastlog.h"
-#endif
-namespace k2r {
 
 // ======================================================================================================
 // The chunk encoder.  PADDED: rows or cols < sidelen (or not a multiple of 8 blocks).  VEC: int32 (1), float32 (2) or
@@ -969,8 +942,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             sh.err = 0;
             sh.stI = 0;
             sh.stQ = 0;
-            sh.f_top = 0;
-            sh.f_flags = 0;
             for (int i = 0; i < 6; i++) sh.fault[i] = 0;
             for (int i = 0; i < NPROF; i++) sh.prof[i] = 0;
             if (cap >= 6) {
@@ -984,38 +955,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     if (!EX::kSim) ex.par([&](int tid, EncRegs&) { if (tid == 0) sh.prof_last = clock64(); });
 #endif
 
-    // The fast log path (k2r_fastlog.h) is tried first for every instant that has a compact snapshot to be compared with;
-    // when it declines (the instant becomes a Snapshot, wide values, ...) the general path below encodes the instant.
-    constexpr bool kFast = K2R_FASTLOG && !PADDED && C::NT >= 64;
-    bool last_general = true;   // the general path's last phase has no closing barrier
-    uint32_t fast_fail = 0, fast_skip = 0, n_fast = 0;
+    uint32_t n_fast = 0;
     for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
         const bool have_s = inst > 0;
-#if K2R_FASTLOG
-        if constexpr (kFast) {
-            if (have_s && s_cmp && !(ta.flags & 1u) && fast_skip == 0) {
-                if (last_general) ex.barrier();
-                last_general = false;
-                uint32_t fsize = 0;
-                if (fast_log_instant<C, VEC>(ex, ta, inst, scmp, s_base, out + off, cap - off, blk_count - 1 == 254, fsize)) {
-                    n_log++;
-                    n_fast++;
-                    fast_fail = 0;
-                    off += fsize;
-                    blk_count++;
-                    continue;
-                }
-                // declined: back off when it keeps declining (data whose instants all become Snapshots, or are all wide)
-                fast_fail++;
-                if (fast_fail >= 2) fast_skip = fast_fail >= 5 ? 8u : (1u << (fast_fail - 2));
-            } else if (fast_skip) {
-                fast_skip--;
-            }
-        }
-#endif
-        (void)kFast; (void)fast_fail; (void)fast_skip; (void)last_general;
-        last_general = true;
-
         // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
         // Nothing but four per-height-2 summaries survives this phase in registers: cells are re-read on
         // demand at emission, and only under visited subtrees (sparse for logs).

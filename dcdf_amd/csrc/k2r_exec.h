@@ -15,6 +15,15 @@ namespace k2r {
 
 constexpr int MAX_SCAN_FIELDS = 16;  // 32-bit words per thread that scan<>/reduce<> can combine
 
+// a * b for operands below 2^24 (one full-rate instruction on the card)
+K2R_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
+
 #if defined(__HIPCC__)
 
 template <class SH, class TR, int NT>
@@ -146,67 +155,6 @@ struct GpuExec {
     }
 
 
-    // ---- SIMT section: the body is ordinary per-lane code that uses the wave primitives below.  All 64 lanes of a
-    // wave reach every primitive together (no divergence around them).  The sequential context runs such a body on
-    // fibers that rendezvous at the primitives (tests/sim), so the very same source is checked on a CPU. ----
-    template <class F>
-    __device__ __forceinline__ void simt(F&& f) {
-        f(tid);
-    }
-    __device__ __forceinline__ void sync(int) { lds_barrier(); }
-    __device__ __forceinline__ void w_fence(int) { __builtin_amdgcn_wave_barrier(); }  // orders this wave's LDS traffic for the compiler
-    __device__ __forceinline__ uint64_t w_ballot(int, bool p) const { return __builtin_amdgcn_ballot_w64(p); }
-    // set bits of m below this lane
-    __device__ __forceinline__ uint32_t w_mbcnt(int, uint64_t m) const {
-        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    }
-    __device__ __forceinline__ int32_t w_lane(int, int32_t v, int lane) const { return __builtin_amdgcn_readlane(v, lane); }
-    __device__ __forceinline__ int32_t w_first(int, int32_t v) const { return __builtin_amdgcn_readfirstlane(v); }
-    // value of the previous lane; the first lane of each row of 16 gets its own value back (DPP row_shr:1)
-    __device__ __forceinline__ int32_t w_prev(int, int32_t v) const { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }
-    // min / max over aligned groups of G = 4 or 16 lanes, result in every lane of the group (quad_perm swaps, then
-    // row_half_mirror / row_mirror): 2 or 4 DPP-fused VALU operations, no LDS traffic
-    template <int G>
-    __device__ __forceinline__ int32_t w_gmin(int, int32_t x) const {
-        int32_t y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
-        x = y < x ? y : x;
-        y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);          // quad_perm:[2,3,0,1]
-        x = y < x ? y : x;
-        if (G == 16) x = w_gmin16_from4(0, x);
-        return x;
-    }
-    template <int G>
-    __device__ __forceinline__ int32_t w_gmax(int, int32_t x) const {
-        int32_t y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);
-        x = y > x ? y : x;
-        y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);
-        x = y > x ? y : x;
-        if (G == 16) x = w_gmax16_from4(0, x);
-        return x;
-    }
-    // the same over rows of 16, given values already reduced over quads
-    __device__ __forceinline__ int32_t w_gmin16_from4(int, int32_t x) const {
-        int32_t y = __builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, true);  // row_half_mirror
-        x = y < x ? y : x;
-        y = __builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, true);          // row_mirror
-        return y < x ? y : x;
-    }
-    __device__ __forceinline__ int32_t w_gmax16_from4(int, int32_t x) const {
-        int32_t y = __builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, true);
-        x = y > x ? y : x;
-        y = __builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, true);
-        return y > x ? y : x;
-    }
-    // inclusive prefix sum inside each row of 16 lanes (row_shr 1, 2, 4, 8 with zero fill)
-    __device__ __forceinline__ uint32_t w_rowscan(int, uint32_t v) const {
-        int x = (int)v;
-        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
-        return (uint32_t)x;
-    }
-    __device__ __forceinline__ uint32_t w_iscan(int, uint32_t v) const { return wave_incl_scan(v); }
     __device__ __forceinline__ uint32_t lds_or_nr(uint32_t* p, uint32_t v) { atomicOr(p, v); return 0; }
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
@@ -249,95 +197,8 @@ struct GpuExec {
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 }  // namespace k2r
-#include <ucontext.h>
-
-#include <functional>
-#include <memory>
 #include <vector>
 namespace k2r {
-
-// Cooperative SIMT emulation for SimExec::simt: one fiber per logical thread; fibers of a wave rendezvous at the wave
-// primitives (every lane deposits a value, then all of them read the 64 values), all fibers at sync().
-struct SimtSched {
-    int n = 0, cur = 0, lanes = 64;
-    std::vector<ucontext_t> ctx;
-    ucontext_t main_ctx;
-    std::vector<std::unique_ptr<char[]>> stacks;
-    std::vector<char> done;
-    std::function<void(int)> body;
-    struct WaveSlot {
-        uint64_t buf[2][64];
-        int arrived = 0;
-        uint32_t gen = 0;
-    };
-    std::vector<WaveSlot> waves;
-    int bar_arrived = 0;
-    uint32_t bar_gen = 0;
-    static SimtSched*& current() {
-        static thread_local SimtSched* s = nullptr;
-        return s;
-    }
-    static void tramp() {
-        SimtSched* s = current();
-        const int id = s->cur;
-        s->body(id);
-        s->done[id] = 1;
-    }
-    void yield() { swapcontext(&ctx[cur], &main_ctx); }
-    void run(int nthreads, std::function<void(int)> f) {
-        constexpr size_t kStack = 256 * 1024;
-        n = nthreads;
-        lanes = n < 64 ? n : 64;
-        body = std::move(f);
-        ctx.resize(n);
-        done.assign(n, 0);
-        stacks.resize(n);
-        waves.assign((n + 63) / 64, WaveSlot());
-        bar_arrived = 0;
-        SimtSched* prev = current();
-        current() = this;
-        for (int i = 0; i < n; i++) {
-            if (!stacks[i]) stacks[i].reset(new char[kStack]);
-            getcontext(&ctx[i]);
-            ctx[i].uc_stack.ss_sp = stacks[i].get();
-            ctx[i].uc_stack.ss_size = kStack;
-            ctx[i].uc_link = &main_ctx;
-            makecontext(&ctx[i], (void (*)())tramp, 0);
-        }
-        int remaining = n;
-        while (remaining > 0) {
-            remaining = 0;
-            for (int i = 0; i < n; i++) {
-                if (done[i]) continue;
-                cur = i;
-                swapcontext(&main_ctx, &ctx[i]);
-                if (!done[i]) remaining++;
-            }
-        }
-        current() = prev;
-    }
-    const uint64_t* gather(int tid, uint64_t v) {
-        WaveSlot& w = waves[tid >> 6];
-        const uint32_t g = w.gen;
-        w.buf[g & 1][tid & 63] = v;
-        if (++w.arrived == lanes) {
-            w.arrived = 0;
-            w.gen++;
-        } else {
-            while (w.gen == g) yield();
-        }
-        return w.buf[g & 1];
-    }
-    void sync_all() {
-        const uint32_t g = bar_gen;
-        if (++bar_arrived == n) {
-            bar_arrived = 0;
-            bar_gen++;
-        } else {
-            while (bar_gen == g) yield();
-        }
-    }
-};
 
 template <class SH, class TR, int NT>
 struct SimExec {
@@ -383,58 +244,6 @@ struct SimExec {
     }
 
 
-    // ---- SIMT section (see GpuExec): fibers + rendezvous ----
-    SimtSched sched;
-    template <class F>
-    void simt(F&& f) {
-        sched.run(NT, [&](int t) { f(t); });
-    }
-    void sync(int) { sched.sync_all(); }
-    void w_fence(int tid) { sched.gather(tid, 0); }
-    uint64_t w_ballot(int tid, bool p) {
-        const uint64_t* a = sched.gather(tid, p ? 1 : 0);
-        uint64_t m = 0;
-        for (int i = 0; i < sched.lanes; i++) m |= (a[i] & 1) << i;
-        return m;
-    }
-    uint32_t w_mbcnt(int tid, uint64_t m) const { return (uint32_t)__builtin_popcountll(m & (((uint64_t)1 << (tid & 63)) - 1)); }
-    int32_t w_lane(int tid, int32_t v, int lane) { return (int32_t)(uint32_t)sched.gather(tid, (uint32_t)v)[lane]; }
-    int32_t w_first(int tid, int32_t v) { return w_lane(tid, v, 0); }
-    int32_t w_prev(int tid, int32_t v) {
-        const uint64_t* a = sched.gather(tid, (uint32_t)v);
-        const int l = tid & 63;
-        return (l & 15) == 0 ? v : (int32_t)(uint32_t)a[l - 1];
-    }
-    template <int G>
-    int32_t w_gmin(int tid, int32_t v) {
-        const uint64_t* a = sched.gather(tid, (uint32_t)v);
-        const int l0 = (tid & 63) & ~(G - 1);
-        int32_t r = (int32_t)(uint32_t)a[l0];
-        for (int i = 1; i < G; i++) r = (int32_t)(uint32_t)a[l0 + i] < r ? (int32_t)(uint32_t)a[l0 + i] : r;
-        return r;
-    }
-    template <int G>
-    int32_t w_gmax(int tid, int32_t v) {
-        const uint64_t* a = sched.gather(tid, (uint32_t)v);
-        const int l0 = (tid & 63) & ~(G - 1);
-        int32_t r = (int32_t)(uint32_t)a[l0];
-        for (int i = 1; i < G; i++) r = (int32_t)(uint32_t)a[l0 + i] > r ? (int32_t)(uint32_t)a[l0 + i] : r;
-        return r;
-    }
-    int32_t w_gmin16_from4(int tid, int32_t v) { return w_gmin<16>(tid, v); }
-    int32_t w_gmax16_from4(int tid, int32_t v) { return w_gmax<16>(tid, v); }
-    uint32_t w_rowscan(int tid, uint32_t v) {
-        const uint64_t* a = sched.gather(tid, v);
-        uint32_t r = 0;
-        for (int i = (tid & 63) & ~15; i <= (tid & 63); i++) r += (uint32_t)a[i];
-        return r;
-    }
-    uint32_t w_iscan(int tid, uint32_t v) {
-        const uint64_t* a = sched.gather(tid, v);
-        uint32_t r = 0;
-        for (int i = 0; i <= (tid & 63); i++) r += (uint32_t)a[i];
-        return r;
-    }
     uint32_t lds_or_nr(uint32_t* p, uint32_t v) {
         *p |= v;
         return 0;

@@ -7,7 +7,7 @@
 namespace k2r {
 
 struct EncClass {  // one kernel instantiation
-    int log2s;     // 3..8
+    int log2s;     // 4..8 (sidelen 8 and below go to the universal kernel)
     bool padded;
     int vec;       // 0 generic loads, 1 int32 vector loads, 2 float32, 3 int64, 4 float64 vector loads (k2r_encode.h load_sub16)
     bool operator==(const EncClass& o) const { return log2s == o.log2s && padded == o.padded && vec == o.vec; }
