@@ -155,6 +155,21 @@ struct GpuExec {
     }
 
 
+    // Slots for a whole wave with ONE LDS atomic: every lane asks for v >= 0 units (several counters may share the word
+    // as bit fields); a wave scan gives each lane its offset, one lane adds the wave's total to *ctr.  Returns the lane's
+    // first unit.  All lanes of the wave must call it together.
+    __device__ __forceinline__ uint32_t wave_alloc(uint32_t* ctr, uint32_t v) {
+        constexpr int W = NT < 64 ? NT : 64;
+        const uint32_t incl = wave_incl_scan(v);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, W - 1);
+        // (spelled out: handed an atomicAdd, the compiler's atomic optimizer wraps it in its own lane bookkeeping)
+        const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)ctr;
+        uint32_t base = 0;
+        if ((tid & 63) == 0)
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(total) : "memory");
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        return base + incl - v;
+    }
     __device__ __forceinline__ uint32_t lds_or_nr(uint32_t* p, uint32_t v) { atomicOr(p, v); return 0; }
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
@@ -244,6 +259,11 @@ struct SimExec {
     }
 
 
+    uint32_t wave_alloc(uint32_t* ctr, uint32_t v) {  // (threads run one after the other: the counter is the prefix)
+        const uint32_t o = *ctr;
+        *ctr = o + v;
+        return o;
+    }
     uint32_t lds_or_nr(uint32_t* p, uint32_t v) {
         *p |= v;
         return 0;
