@@ -209,6 +209,7 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
         const uint32_t nt = (uint32_t)e->class_tiles[ci].size();
         const int per_cu = encode_blocks_per_cu(c);
         uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)rt.cus * (uint64_t)per_cu);
+        if (const char* mw = std::getenv("K2R_MAX_WGS")) g = std::min<uint32_t>(g, (uint32_t)std::max(1, std::atoi(mw)));  // diagnostics
         e->grid.push_back(std::max(1u, g));
         e->order_off.push_back(order_total);
         order_total += nt;

@@ -675,7 +675,6 @@ struct EncShared : EncPool<C> {
     // per-thread exclusive prefixes for stash emission (records find their owner's): [0] I1 | I2 << 16 of the winner,
     // [1] second bytes of cell values, [2] second bytes of height-1 values: Lmax | Lmin << 16
     uint32_t pfx[3][C::NBLK];
-    uint32_t ttV[C::H + 2], ttI[C::H + 2], ttZ[C::H + 2];  // the winner's level offsets, for run-time heights
     uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
     uint32_t tbP[C::TBW + 1];           // per-word exclusive popcount prefix of the winner's flags
     uint32_t ttR[C::H + 2];             // rank (over those flags) of the first node of height h
@@ -1383,10 +1382,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         ex.stamp(0);  // phase 1: load + thread-local analysis
 
         // ================= phase 2: heights 4..H in LDS (snapshot.rs:476-497, log.rs:776-806) ==========
+        // A level with more than 64 nodes is spread over the workgroup (one barrier); the levels above it -- 64, 16, 4, 1
+        // nodes -- are all done by the first wave, one after the other with no workgroup barrier in between (the LDS
+        // serves one wave's accesses in order), while the other waves go ahead to the barrier that closes the phase.
         for (int h = 4; h <= H; h++) {
             const int n_h = 1 << (2 * (H - h));
             const int co = C::top_off(h - 1), po = C::top_off(h);
-            ex.par([&](int tid, EncRegs&) {
+            auto level = [&](int tid, EncRegs&) {
                 for (int j = tid; j < n_h; j += NT) {
                     const int c = co + 4 * j;
                     sh.tmin[po + j] = min4(sh.tmin[c], sh.tmin[c + 1], sh.tmin[c + 2], sh.tmin[c + 3]);
@@ -1402,7 +1404,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                                             : 0u;
                     }
                 }
-            });
+            };
+            if (NT >= 64 && n_h <= 64) {
+                ex.par_wave0(level);
+                if (h == H) ex.barrier();
+            } else {
+                ex.par(level);
+            }
         }
 
         ex.stamp(1);  // phase 2: top of the tree
@@ -1639,12 +1647,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     pl.isize = size;
                     // a Log is emitted from the stash when phase 1 managed to record all of it
                     pl.use_stash = (!snap && narrow && 5u * stI + 3u * stQ <= stash_cap && stI == W.Ni[2] && stQ == W.Ni[1]) ? 1u : 0u;
-#pragma unroll
-                    for (int h = 0; h <= H; h++) {
-                        sh.ttV[h] = W.offV[h];
-                        sh.ttI[h] = W.offI[h];
-                        sh.ttZ[h] = W.offZ[h];
-                    }
                     uint32_t rr = 0;
 #pragma unroll
                     for (int h = 4; h <= H; h++) {
@@ -1862,7 +1864,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 };
                 uint32_t vrank = 0;
                 if (h < H) vrank = 4 * (trank(tbit(h + 1, j >> 2)) - sh.ttR[h + 1]) + (j & 3);
-                const uint32_t idx = sh.ttV[h] + vrank;
+                const uint32_t idx = TT.offV[h] + vrank;
                 const uint32_t irank = (h == 3) ? unpackI(3, pLo, 0) : trank(tbit(h, j)) - sh.ttR[h];
                 const uint32_t zv = zz32(as_snapshot ? snap_vmax(h, j) : log_vmax(h, j));
                 emit_val<0, MODE>(ex, sinkV, idx, zv, tid);
@@ -1873,15 +1875,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 if (p) {
                     bm_set(ex, sh.bmT, guard_pos(ex, idx, 1, TT.LT, kGuardTOwn));
                     const uint32_t zm = zz32(as_snapshot ? snap_vmin(h, j) : log_vmin(h, j));
-                    emit_val<1, MODE>(ex, sinkM, sh.ttI[h] + irank, zm, tid);
+                    emit_val<1, MODE>(ex, sinkM, TT.offI[h] + irank, zm, tid);
                     if (MODE == EM_P0) {
-                        r.pa[3 * slot + 1] = sh.ttI[h] + irank;
+                        r.pa[3 * slot + 1] = TT.offI[h] + irank;
                         r.pa[2] |= (zm >> 8) << (16 * slot + 8);
                     }
                 } else if (!as_snapshot) {
                     const int a = C::top_off(h) + (int)j;
                     const bool e = !top_inval(h, j) && sh.tmin[a] != sh.tmax[a];  // not uniform => equal
-                    if (e) bm_set(ex, sh.bmE, guard_pos(ex, sh.ttZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
+                    if (e) bm_set(ex, sh.bmE, guard_pos(ex, TT.offZ[h] + vrank - irank, 1, TT.LT - TT.M0, kGuardEOwn));
                 }
             };
             const uint32_t wt = opaque((uint32_t)tid);

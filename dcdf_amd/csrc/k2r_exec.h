@@ -54,6 +54,14 @@ struct GpuExec {
         f(tid, r);
     }
     __device__ __forceinline__ void barrier() { lds_barrier(); }
+    // A phase for the first wave only, ordered against its own earlier / later LDS traffic but with no workgroup barrier:
+    // the LDS executes one wave's instructions in order, so a chain of such phases hands data from lane to lane safely.
+    // The caller closes the chain with barrier().
+    template <class F>
+    __device__ __forceinline__ void par_wave0(F&& f) {
+        if (tid < 64) f(tid, r);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     // diagnostic builds only: attribute the cycles since the previous stamp to phase k (thread 0's view)
     __device__ __forceinline__ void stamp(int k) {
 #ifdef K2R_PROFILE
@@ -91,6 +99,37 @@ struct GpuExec {
         return (uint32_t)x;
     }
 
+    // The same for N independent values, step by step across all of them: a DPP instruction cannot issue right behind the
+    // VALU instruction that produced its source (two wait states), so N interleaved chains run back to back where N
+    // separate scans are half s_nop.
+    template <int N>
+    __device__ __forceinline__ static void wave_incl_scan_n(int (&x)[N]) {
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x111, 0xf, 0xf, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x112, 0xf, 0xf, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x114, 0xf, 0xf, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x118, 0xf, 0xf, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x142, 0xa, 0xf, false);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x143, 0xc, 0xf, false);
+    }
+    // ... and the prefix sums inside each row of 16 lanes only (the first four steps)
+    template <int N>
+    __device__ __forceinline__ static void row_incl_scan_n(int (&x)[N]) {
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x111, 0xf, 0xf, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x112, 0xf, 0xf, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x114, 0xf, 0xf, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x118, 0xf, 0xf, true);
+    }
+
     // workgroup sum of r.sc[F0..F0+NF) -> sh.tot[F0..F0+NF) (no prefixes): wave totals through sh.wsum, then a 16-lane
     // row reduction of them (no atomics)
     template <int NF, int F0 = 0>
@@ -99,20 +138,22 @@ struct GpuExec {
         constexpr int NW = NT < 64 ? 1 : NT / 64;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        int inc[NF];
 #pragma unroll
-        for (int f = F0; f < F0 + NF; f++) {
-            const uint32_t inc = wave_incl_scan(r.sc[f]);
-            if (lane == W - 1) sh.wsum[wave][f] = inc;
+        for (int f = 0; f < NF; f++) inc[f] = (int)r.sc[F0 + f];
+        wave_incl_scan_n(inc);
+        if (lane == W - 1) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) sh.wsum[wave][F0 + f] = (uint32_t)inc[f];
         }
         lds_barrier();
+        int x[NF];
 #pragma unroll
-        for (int f = F0; f < F0 + NF; f++) {
-            int x = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
-            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
-            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
-            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
-            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
-            if (tid == NW - 1) sh.tot[f] = (uint32_t)x;
+        for (int f = 0; f < NF; f++) x[f] = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][F0 + f] : 0;
+        row_incl_scan_n(x);
+        if (tid == NW - 1) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) sh.tot[F0 + f] = (uint32_t)x[f];
         }
         lds_barrier();
     }
@@ -126,12 +167,16 @@ struct GpuExec {
         constexpr int W = NT < 64 ? NT : 64;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        int inc[NF];
 #pragma unroll
-        for (int f = 0; f < NF; f++) {
-            const uint32_t inc = wave_incl_scan(r.sc[f]);
-            if (lane == W - 1) sh.wsum[wave][f] = inc;
-            r.sc[f] = inc - r.sc[f];
+        for (int f = 0; f < NF; f++) inc[f] = (int)r.sc[f];
+        wave_incl_scan_n(inc);
+        if (lane == W - 1) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) sh.wsum[wave][f] = (uint32_t)inc[f];
         }
+#pragma unroll
+        for (int f = 0; f < NF; f++) r.sc[f] = (uint32_t)inc[f] - r.sc[f];
         lds_barrier();
     }
     static constexpr int planner() { return 0; }
@@ -142,15 +187,14 @@ struct GpuExec {
         constexpr int NW = NT < 64 ? 1 : NT / 64;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        int x[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) x[f] = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
+        row_incl_scan_n(x);
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            int x = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
-            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
-            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
-            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
-            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
-            tot[f] = (uint32_t)__builtin_amdgcn_readlane(x, NW - 1);
-            r.sc[f] += wave == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane(x, wave - 1);
+            tot[f] = (uint32_t)__builtin_amdgcn_readlane(x[f], NW - 1);
+            r.sc[f] += wave == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane(x[f], wave - 1);
         }
     }
 
@@ -183,25 +227,26 @@ struct GpuExec {
         constexpr int NW = NT < 64 ? 1 : NT / 64;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        uint32_t incl[NF];
+        int incl[NF];
 #pragma unroll
-        for (int f = 0; f < NF; f++) {
-            incl[f] = wave_incl_scan(r.sc[f]);
-            if (lane == W - 1) sh.wsum[wave][f] = incl[f];
+        for (int f = 0; f < NF; f++) incl[f] = (int)r.sc[f];
+        wave_incl_scan_n(incl);
+        if (lane == W - 1) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) sh.wsum[wave][f] = (uint32_t)incl[f];
         }
         lds_barrier();
         // the NW (<= 16) wave totals of a field sit in lanes 0..NW-1 of every wave: a 4-step row scan turns them into
         // the wave bases -- one 16-lane LDS read per field instead of NW broadcast reads
+        int x[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) x[f] = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
+        row_incl_scan_n(x);
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            int x = (lane < NW) ? (int)sh.wsum[lane < NW ? lane : 0][f] : 0;
-            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
-            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
-            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
-            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(x, NW - 1);
-            const uint32_t base = wave == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane(x, wave - 1);
-            r.sc[f] = base + incl[f] - r.sc[f];
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(x[f], NW - 1);
+            const uint32_t base = wave == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane(x[f], wave - 1);
+            r.sc[f] = base + (uint32_t)incl[f] - r.sc[f];
             if (TOT && tid == 0) sh.tot[f] = tot;
         }
         if (TOT) lds_barrier();
@@ -234,6 +279,10 @@ struct SimExec {
         for (int t = 0; t < NT; t++) f(t, regs[t]);
     }
     void barrier() {}
+    template <class F>
+    void par_wave0(F&& f) {
+        for (int t = 0; t < (NT < 64 ? NT : 64); t++) f(t, regs[t]);
+    }
     void barrier_global() {}
     void stamp(int) {}
     template <class T>
