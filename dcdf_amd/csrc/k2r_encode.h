@@ -319,146 +319,46 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
     }
 }
 
-// ---- packed 16-bit arithmetic (two values per 32-bit word; one VALU instruction each on the card) ----------------
-// low halves of a and b: (a & 0xffff) | b << 16
-K2R_HD uint32_t pk_lo16(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_perm(b, a, 0x05040100u);
-#else
-    return (a & 0xffffu) | (b << 16);
-#endif
-}
-// half-wise a - b (mod 2^16)
-K2R_HD uint32_t pk_sub16(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
-#else
-    return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16);
-#endif
-}
-// per half: 1 if the int16 value needs a second Dac byte (zig-zag > 0xff  <=>  v < -128 || v > 127), else 0
-K2R_HD uint32_t pk_long2(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // (written out: left to itself the compiler turns min(x >> 8, 1) into two 16-bit compares and two selects)
-    uint32_t y, z, r;
-    asm("v_pk_add_u16 %0, %1, %2" : "=v"(y) : "v"(x), "v"(0x00800080u));
-    asm("v_pk_lshrrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(z) : "v"(y));  // (the constant comes from the low half for both lanes)
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(z), "v"(0x00010001u));
-    return r;
-#else
-    const uint32_t lo = ((x + 128u) & 0xffffu) >> 8, hi = (((x >> 16) + 128u) & 0xffffu) >> 8;
-    return (lo ? 1u : 0u) | ((hi ? 1u : 0u) << 16);
-#endif
-}
-// acc + low half of x + high half of x
-K2R_HD uint32_t pk_sum_acc(uint32_t x, uint32_t acc) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_sad_u16(x, 0u, acc);
-#else
-    return acc + (x & 0xffffu) + (x >> 16);
-#endif
-}
-K2R_HD uint32_t rot16(uint32_t x) { return (x >> 16) | (x << 16); }
-K2R_HD int32_t sext16(uint32_t x) { return (int32_t)(int16_t)(x & 0xffffu); }
-
-// ---- the per-workgroup copy of the open block's snapshot instant (global scratch; see encode_chunk) ----------------
-// SCMP_WORDS 32-bit words per thread:
-//   cells  [(j * NT + tid) * 8, +8)            the 16 cells of sub-block j of thread tid, the LOW 16 BITS of each stored value,
-//                                              two per word in local Morton order (a wave reads 2 KB contiguous)
-//   quads  32 * NT + [(j * NT + tid) * 4, +4)  per quad of that sub-block: low 16 bits of its maximum | of its minimum << 16
-//   nodes  48 * NT + [tid * 8, +8)             words 0-3: the same pair for the four height-2 nodes, 4 / 5: minimum / maximum of
-//                                              the thread's 8x8 block (full int32)
-// Differences against the snapshot are taken half-wise on the low 16 bits: exact whenever the true difference fits int16,
-// which the packed phase 1 verifies per block from the full-width extremes.  The scalar phase 1 rebuilds the absolute value
-// from `base` (the copy is only kept for snapshots whose range is below 2^16).
-constexpr int SCMP_WORDS = 56;
+// The compact copy of a block's snapshot instant (see encode_chunk): 16 cells of sub-block j of thread tid, uint16
+// offsets from `base`: words [(j * NT + tid) * 8, +8) (a wave reads 2 KB contiguous per sub-block).
 template <class C>
 K2R_HD uint32_t compact_slot(int tid, int j) {
     return (uint32_t)j * (uint32_t)C::NT + (uint32_t)tid;
 }
 template <class C>
-K2R_HD void load_compact_raw(const uint32_t* scmp, int tid, int j, uint32_t (&w)[8]) {
+K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int32_t (&dst)[16]) {
+    const uint32_t* p = scmp + (size_t)compact_slot<C>(tid, j) * 8;
+    uint32_t w[8];
 #if defined(__HIP_DEVICE_COMPILE__)
     // wave-uniform base (SGPR pair) + 32-bit byte offset per thread: no 64-bit address arithmetic on the VALU
     typedef __attribute__((address_space(1))) const char* gptr;
-    uint32_t ob = compact_slot<C>(tid, j) * 32u;
-    asm volatile("" : "+v"(ob));  // (recomputed per use: hoisted out of the instant loop the 64-bit addresses get spilled)
+    const uint32_t ob = compact_slot<C>(tid, j) * 32u;
     const uint4 a = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob);
     const uint4 b = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob + 16);
+    (void)p;
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
     w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 #else
-    const uint32_t* p = scmp + (size_t)compact_slot<C>(tid, j) * 8;
     for (int i = 0; i < 8; i++) w[i] = p[i];
 #endif
-}
-template <class C>
-K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int32_t (&dst)[16]) {
-    uint32_t w[8];
-    load_compact_raw<C>(scmp, tid, j, w);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        dst[2 * i] = base + (int32_t)((w[i] - (uint32_t)base) & 0xffffu);
-        dst[2 * i + 1] = base + (int32_t)(((w[i] >> 16) - (uint32_t)base) & 0xffffu);
+        dst[2 * i] = base + (int32_t)(w[i] & 0xffffu);
+        dst[2 * i + 1] = base + (int32_t)(w[i] >> 16);
     }
 }
-// the quad words of sub-block j
 template <class C>
-K2R_HD void load_quad_table(const uint32_t* scmp, int tid, int j, uint32_t (&sq)[4]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(1))) const char* gptr;
-    uint32_t ob = 128u * (uint32_t)C::NT + compact_slot<C>(tid, j) * 16u;
-    asm volatile("" : "+v"(ob));
-    const uint4 a = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob);
-    sq[0] = a.x; sq[1] = a.y; sq[2] = a.z; sq[3] = a.w;
-#else
-    const uint32_t* p = scmp + 32 * (size_t)C::NT + (size_t)compact_slot<C>(tid, j) * 4;
-    for (int i = 0; i < 4; i++) sq[i] = p[i];
-#endif
-}
-template <class C>
-K2R_HD void load_node_table(const uint32_t* scmp, int tid, uint32_t (&th)[4], int32_t& smn3, int32_t& smx3) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(1))) const char* gptr;
-    uint32_t ob = 192u * (uint32_t)C::NT + (uint32_t)tid * 32u;
-    asm volatile("" : "+v"(ob));
-    const uint4 a = *(__attribute__((address_space(1))) const uint4*)((gptr)scmp + ob);
-    const uint2 b = *(__attribute__((address_space(1))) const uint2*)((gptr)scmp + ob + 16);
-    th[0] = a.x; th[1] = a.y; th[2] = a.z; th[3] = a.w;
-    smn3 = (int32_t)b.x; smx3 = (int32_t)b.y;
-#else
-    const uint32_t* p = scmp + 48 * (size_t)C::NT + (size_t)tid * 8;
-    for (int i = 0; i < 4; i++) th[i] = p[i];
-    smn3 = (int32_t)p[4];
-    smx3 = (int32_t)p[5];
-#endif
-}
-// writes sub-block j of a new snapshot instant: its cells and its quad words; returns the height-2 word
-template <class C>
-K2R_HD uint32_t store_compact(uint32_t* scmp, int tid, int j, const int32_t (&src)[16], int32_t& mn2, int32_t& mx2) {
+K2R_HD void store_compact(uint32_t* scmp, int tid, int j, int32_t base, const int32_t (&src)[16]) {
     uint32_t* p = scmp + (size_t)compact_slot<C>(tid, j) * 8;
-    uint32_t* t = scmp + 32 * (size_t)C::NT + (size_t)compact_slot<C>(tid, j) * 4;
-    uint32_t w[8], sq[4];
+    uint32_t w[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) w[i] = pk_lo16((uint32_t)src[2 * i], (uint32_t)src[2 * i + 1]);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int32_t mn1 = min4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
-        const int32_t mx1 = max4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
-        sq[q] = pk_lo16((uint32_t)mx1, (uint32_t)mn1);
-        mn2 = q == 0 ? mn1 : (mn1 < mn2 ? mn1 : mn2);
-        mx2 = q == 0 ? mx1 : (mx1 > mx2 ? mx1 : mx2);
-    }
+    for (int i = 0; i < 8; i++) w[i] = (uint32_t)(src[2 * i] - base) | ((uint32_t)(src[2 * i + 1] - base) << 16);
 #if defined(__HIP_DEVICE_COMPILE__)
     *(__attribute__((address_space(1))) uint4*)p = uint4{w[0], w[1], w[2], w[3]};
     *(__attribute__((address_space(1))) uint4*)(p + 4) = uint4{w[4], w[5], w[6], w[7]};
-    *(__attribute__((address_space(1))) uint4*)t = uint4{sq[0], sq[1], sq[2], sq[3]};
 #else
     for (int i = 0; i < 8; i++) p[i] = w[i];
-    for (int i = 0; i < 4; i++) t[i] = sq[i];
 #endif
-    return pk_lo16((uint32_t)mx2, (uint32_t)mn2);
 }
 
 // Returns v, but opaque to the optimizer.  Everything derived from the thread index alone (block origin, the top
@@ -679,9 +579,7 @@ struct EncShared : EncPool<C> {
     uint32_t tbP[C::TBW + 1];           // per-word exclusive popcount prefix of the winner's flags
     uint32_t ttR[C::H + 2];             // rank (over those flags) of the first node of height h
     uint32_t nlistV, nlistM;
-    uint32_t stI, stQ;  // stash record counters (scalar phase 1)
-    uint32_t stQI;      // ... of the packed phase 1: Q records | I records << 16, one atomic per wave and sub-block
-    uint32_t p1bad;     // packed phase 1: some difference does not fit int16, the instant is analysed again by the scalar one
+    uint32_t stI, stQ;  // stash record counters
     InstPlan<C> pl;
     int32_t err;
     uint32_t work;
@@ -1043,8 +941,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             sh.err = 0;
             sh.stI = 0;
             sh.stQ = 0;
-            sh.stQI = 0;
-            sh.p1bad = 0;
             for (int i = 0; i < 6; i++) sh.fault[i] = 0;
             for (int i = 0; i < NPROF; i++) sh.prof[i] = 0;
             if (cap >= 6) {
@@ -1058,173 +954,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     if (!EX::kSim) ex.par([&](int tid, EncRegs&) { if (tid == 0) sh.prof_last = clock64(); });
 #endif
 
-    uint32_t n_fast = 0;                 // instants analysed by the packed phase 1
-    uint32_t p1_skip = 0, p1_fail = 0;   // ... its back-off after an instant it had to hand to the scalar one
+    uint32_t n_fast = 0;
     for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
         const bool have_s = inst > 0;
-        // ================= phase 1, packed form =========================================================
-        // For an instant that has a 16-bit snapshot copy to be compared with (every instant of a block but its first, on
-        // unpadded tiles): the same analysis as the scalar phase 1 below, with the same results in registers, LDS and the
-        // stash, but on 16-bit pairs -- differences, their equality tests, the quad / node values of the log and the
-        // second-byte counts take one VALU instruction per TWO values -- with the snapshot's own extremes read from the
-        // tables left by its emission instead of recomputed, and with ONE stash allocation per wave and sub-block (a wave
-        // scan of the lanes' record counts, then a single LDS atomic) instead of one per quad.  Valid when every
-        // difference fits int16, which each thread verifies from its block's extremes; otherwise sh.p1bad is raised and the
-        // scalar phase 1 analyses the instant again (and this form pauses for a few instants).
-        // (4-byte element types only: with 8-byte rows in flight as well the packed form does not fit the 128 registers)
-        bool p1_done = false;
-        if (!PADDED && VEC <= 2 && have_s && s_cmp && !(ta.flags & 1u)) {
-            if (p1_skip != 0) {
-                p1_skip--;
-            } else {
-                ex.par([&](int tid, EncRegs& r) {
-                    uint32_t r0, c0;
-                    blk_origin(tid, r0, c0);
-                    int32_t err = 0;
-                    uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0;
-                    uint32_t cL0 = 0, cL1 = 0, mL1 = 0, mL2 = 0, pend2 = 0;  // second-byte counts (see the scalar form's `lc`)
-                    int32_t mn3 = 0, mx3 = 0;
-                    uint32_t eqbits = 0, eqall = 1, cntbits = 0, u2 = 0, df2_0 = 0;
-                    uint32_t th[4];
-                    int32_t smn3, smx3;
-                    load_node_table<C>(scmp, tid, th, smn3, smx3);
-                    const uint32_t capQ = stash_cap / 3u, capI = stash_cap / 5u;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        sched_fence();
-                        int32_t t16[16];
-                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, err);
-                        uint32_t w[8], sq[4];
-                        load_compact_raw<C>(scmp, tid, j, w);
-                        load_quad_table<C>(scmp, tid, j, sq);
-                        int32_t mn1[4], mx1[4];
-                        uint32_t p01[4], p23[4], recw[4], cpre[4];
-                        bool P1L[4];
-                        bool eq1all = true;
-                        uint32_t bS = 0, bL = 0, acc2 = 0;  // acc2: long Lmax values (low half), long Lmin values of internal quads
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            mn1[q] = min4(t16[4 * q], t16[4 * q + 1], t16[4 * q + 2], t16[4 * q + 3]);
-                            mx1[q] = max4(t16[4 * q], t16[4 * q + 1], t16[4 * q + 2], t16[4 * q + 3]);
-                            const bool P1S = mn1[q] != mx1[q];
-                            p01[q] = pk_sub16(pk_lo16((uint32_t)t16[4 * q], (uint32_t)t16[4 * q + 1]), w[2 * q]);          // log.rs:751
-                            p23[q] = pk_sub16(pk_lo16((uint32_t)t16[4 * q + 2], (uint32_t)t16[4 * q + 3]), w[2 * q + 1]);
-                            const bool eq1 = p01[q] == p23[q] && p01[q] == rot16(p01[q]);                                  // log.rs:780,805
-                            P1L[q] = P1S && !eq1;                                                                         // log.rs:137-152
-                            recw[q] = pk_sub16(pk_lo16((uint32_t)mx1[q], (uint32_t)mn1[q]), sq[q]);                        // log.rs:133,148
-                            bS = (bS << 1) | (P1S ? 1u : 0u);
-                            bL = (bL << 1) | (P1L[q] ? 1u : 0u);
-                            eq1all = eq1all && eq1;
-                            const uint32_t Lc = pk_long2(p01[q]) + pk_long2(p23[q]);
-                            cpre[q] = cL0;
-                            cL0 = pk_sum_acc(P1L[q] ? Lc : 0u, cL0);
-                            const uint32_t Lr = pk_long2(recw[q]);
-                            acc2 += P1L[q] ? Lr : (Lr & 0xffffu);
-                        }
-                        const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
-                        const int32_t mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
-                        mn3 = j == 0 ? mn2 : (mn2 < mn3 ? mn2 : mn3);
-                        mx3 = j == 0 ? mx2 : (mx2 > mx3 ? mx2 : mx3);
-                        const bool P2S = mn2 != mx2;
-                        u2 |= (P2S ? 0u : 1u) << j;
-                        sI2 += P2S ? 1u : 0u;
-                        const uint32_t nS = popc32(bS), nq = popc32(bL);
-                        sI1 += nS;
-                        cntbits += (nS << (4 + 3 * j)) + (nq << (16 + 3 * j));
-                        // all sixteen differences equal: four equal quads with one common value
-                        const uint32_t dd = ((p01[0] ^ p01[1]) | (p01[0] ^ p01[2]) | (p01[0] ^ p01[3])) & 0xffffu;
-                        const bool eq2 = eq1all && dd == 0;
-                        if (j == 0) df2_0 = p01[0] & 0xffffu;
-                        eqall &= ((p01[0] ^ df2_0) & 0xffffu) == 0 ? 1u : 0u;
-                        const bool P2L = P2S && !eq2;
-                        // stash slots of this sub-block's records: Q records in the low half, the I record in the high one
-                        const uint32_t at = ex.wave_alloc(&sh.stQI, nq | ((P2L ? 1u : 0u) << 16));
-                        uint32_t mq = at & 0xffffu, ki = at >> 16;
-                        mq = mq + 4u <= capQ ? mq : (capQ >= 4u ? capQ - 4u : 0u);  // (an exhausted pool is noticed by the planner)
-                        ki = ki < capI ? ki : (capI ? capI - 1u : 0u);
-                        const uint32_t pre1 = lI1, mL1_0 = mL1;
-                        uint32_t* qr = sh.pool + ((uint32_t)SH::POOLW - 3u) - mul24(mq, 3u);  // records grow down from the pool's end
-                        uint32_t qh = (uint32_t)tid | (lI1 << 10);
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            if (P1L[q]) {  // Q record: owner, ordinal among the owner's internal quads, the four cell diffs
-                                qr[0] = qh + (cpre[q] << 14);  // (at most 64 second bytes before the block's last quad: 7 bits)
-                                qr[1] = p01[q];
-                                qr[2] = p23[q];
-                            }
-                            qr -= P1L[q] ? 3 : 0;
-                            qh += P1L[q] ? 1u << 10 : 0u;
-                        }
-                        lI1 += nq;
-                        const uint32_t pend1 = acc2 & 0xffffu;
-                        mL1 += acc2 >> 16;
-                        if (P2L) {  // I record: owner, ordinals, T / eqB runs and the Lmax|Lmin pairs of the four quads
-                            uint32_t erun = 0;  // one eqB bit per quad with T = 0, set iff "equal" rather than uniform (log.rs:137-144)
-#pragma unroll
-                            for (int q = 0; q < 4; q++)
-                                if (!((bL >> (3 - q)) & 1u)) erun = (erun << 1) | ((bS >> (3 - q)) & 1u);
-                            uint32_t* p = sh.pool + mul24(ki, 5u);
-                            p[0] = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (bL << 16) | (erun << 20) | ((cL1 & 31u) << 24) | ((mL1_0 & 31u) << 28);
-                            p[1] = recw[0];
-                            p[2] = recw[1];
-                            p[3] = recw[2];
-                            p[4] = recw[3];
-                        }
-                        lI2 += P2L ? 1u : 0u;
-                        const uint32_t d2 = pk_sub16(pk_lo16((uint32_t)mx2, (uint32_t)mn2), th[j]);  // log.rs:133,148
-                        r.d2[j] = d2;
-                        const uint32_t L2 = pk_long2(d2);
-                        cL1 += P2L ? pend1 : 0u;
-                        mL2 += P2L ? L2 >> 16 : 0u;
-                        pend2 += L2 & 0xffffu;
-                        eqbits |= (eq2 ? 1u : 0u) << j;
-                        eqall &= eq2 ? 1u : 0u;
-                    }
-                    if (VEC == 1 && (mn3 < -VALUE_LIMIT || mx3 >= VALUE_LIMIT) && err == 0) err = ERR_RANGE;
-                    sh.tmin[tid] = mn3;
-                    sh.tmax[tid] = mx3;
-                    const bool eq3 = eqall != 0;
-                    const bool PL3 = mn3 != mx3 && !eq3;
-                    // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: inside int16 the half-wise arithmetic was exact
-                    if (mn3 - smx3 < -32768 || mx3 - smn3 > 32767) sh.p1bad = 1;
-                    sh.smin[tid] = smn3;
-                    sh.smax[tid] = smx3;
-                    sh.diff[tid] = sext16(df2_0);
-                    sh.eq[tid] = eq3 ? 1u : 0u;
-                    r.flags = eqbits | cntbits;
-                    r.u2 = u2;
-                    if (tid < C::TBW) {
-                        sh.tbS[tid] = 0;
-                        sh.tbL[tid] = 0;
-                    }
-                    r.sc[0] = sI1 | (sI2 << 16);
-                    r.sc[3] = lI1 | (lI2 << 16);
-                    r.sc[7] = cL0 & 127u;
-                    r.sc[8] = (cL1 & 31u) | ((PL3 ? pend2 & 7u : 0u) << 16);
-                    r.sc[9] = (mL1 & 31u) | ((mL2 & 7u) << 16);
-                    if (err != 0) ex.lds_min(&sh.err, err);
-                });
-                if (ex.uni(sh.p1bad) == 0) {
-                    p1_done = true;
-                    p1_fail = 0;
-                    n_fast++;
-                } else {  // analyse the instant again, exactly; back off while this keeps happening
-                    ex.par([&](int tid, EncRegs&) {
-                        if (tid == 0) {
-                            sh.stQI = 0;
-                            sh.p1bad = 0;
-                        }
-                    });
-                    p1_fail = p1_fail < 5 ? p1_fail + 1 : 5;
-                    p1_skip = (1u << p1_fail) - 1u;
-                }
-            }
-        }
-
         // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
         // Nothing but four per-height-2 summaries survives this phase in registers: cells are re-read on
         // demand at emission, and only under visited subtrees (sparse for logs).
-        if (!p1_done) ex.par([&](int tid, EncRegs& r) {
+        ex.par([&](int tid, EncRegs& r) {
             uint32_t r0, c0;
             blk_origin(tid, r0, c0);
             int32_t err = 0;
@@ -1373,8 +1109,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             if (err != 0) ex.lds_min(&sh.err, err);
         });
         const int32_t perr = ex.uni(sh.err);
-        const uint32_t stQI = ex.uni(sh.stQI);
-        const uint32_t stI = p1_done ? stQI >> 16 : ex.uni(sh.stI), stQ = p1_done ? stQI & 0xffffu : ex.uni(sh.stQ);  // (zeroed again in phase 3)
+        const uint32_t stI = ex.uni(sh.stI), stQ = ex.uni(sh.stQ);  // (zeroed again in phase 3)
         if (perr != 0) {
             status = perr == ERR_RANGE ? (int32_t)ST_UNSUPPORTED : perr;
             break;
@@ -1382,13 +1117,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         ex.stamp(0);  // phase 1: load + thread-local analysis
 
         // ================= phase 2: heights 4..H in LDS (snapshot.rs:476-497, log.rs:776-806) ==========
-        // A level with more than 64 nodes is spread over the workgroup (one barrier); the levels above it -- 64, 16, 4, 1
-        // nodes -- are all done by the first wave, one after the other with no workgroup barrier in between (the LDS
-        // serves one wave's accesses in order), while the other waves go ahead to the barrier that closes the phase.
         for (int h = 4; h <= H; h++) {
             const int n_h = 1 << (2 * (H - h));
             const int co = C::top_off(h - 1), po = C::top_off(h);
-            auto level = [&](int tid, EncRegs&) {
+            ex.par([&](int tid, EncRegs&) {
                 for (int j = tid; j < n_h; j += NT) {
                     const int c = co + 4 * j;
                     sh.tmin[po + j] = min4(sh.tmin[c], sh.tmin[c + 1], sh.tmin[c + 2], sh.tmin[c + 3]);
@@ -1404,13 +1136,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                                             : 0u;
                     }
                 }
-            };
-            if (NT >= 64 && n_h <= 64) {
-                ex.par_wave0(level);
-                if (h == H) ex.barrier();
-            } else {
-                ex.par(level);
-            }
+            });
         }
 
         ex.stamp(1);  // phase 2: top of the tree
@@ -1491,7 +1217,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             if (tid == 0) {
                 sh.stI = 0;
                 sh.stQ = 0;
-                sh.stQI = 0;
             }
             if (wt < (uint32_t)C::NTOPX) {
                 int h;
@@ -1786,7 +1511,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             n_snap++;
             const int32_t rmin = ex.uni(sh.tmin[C::top_off(H)]), rmax = ex.uni(sh.tmax[C::top_off(H)]);
             s_cmp = (int64_t)rmax - (int64_t)rmin <= 65535 && inst + 1 < ta.instants;
-            s_base = rmin;
+            // the 16-bit window of the compact copy is centred on the snapshot's range: the fast log path (k2r_fastlog.h)
+            // needs the LATER instants of the block inside it too, and those drift either way
+            s_base = s_cmp ? rmin - (65535 - (rmax - rmin)) / 2 : rmin;
         } else {
             n_log++;
         }
@@ -2069,18 +1796,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     uint32_t r0, c0;
                     blk_origin(tid, r0, c0);
                     int32_t lerr = 0;
-                    int32_t mn3 = 0, mx3 = 0;
-                    uint32_t* const nt = scmp + 48 * (size_t)NT + (size_t)tid * 8;  // this thread's node words
 #pragma unroll 1
                     for (int j = 0; j < 4; j++) {
-                        int32_t t16[16], mn2 = 0, mx2 = 0;
+                        int32_t t16[16];
                         load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
-                        nt[j] = store_compact<C>(scmp, tid, j, t16, mn2, mx2);
-                        mn3 = j == 0 ? mn2 : (mn2 < mn3 ? mn2 : mn3);
-                        mx3 = j == 0 ? mx2 : (mx2 > mx3 ? mx2 : mx3);
+                        store_compact<C>(scmp, tid, j, s_base, t16);
                     }
-                    nt[4] = (uint32_t)mn3;
-                    nt[5] = (uint32_t)mx3;
                 });
                 ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
             }

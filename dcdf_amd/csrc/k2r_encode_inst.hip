@@ -19,8 +19,8 @@ k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, c
     using C = EncCfg<LOG2S>;
     __shared__ EncShared<C> sh;
     GpuExec<EncShared<C>, EncRegs, C::NT> ex(sh);
-    // per-workgroup global scratch: the two overflow lists and the snapshot copy (SCMP_WORDS 32-bit words per thread)
-    uint64_t* listV = lists + (size_t)blockIdx.x * (C::MAXV + C::MAXT + 2 + (SCMP_WORDS / 2) * C::NT);
+    // per-workgroup global scratch: the two overflow lists and the compact snapshot copy (16 u64 words per thread)
+    uint64_t* listV = lists + (size_t)blockIdx.x * (C::MAXV + C::MAXT + 2 + 16 * C::NT);
     uint64_t* listM = listV + (C::MAXV + 1);
     uint32_t* scmp = (uint32_t*)(listM + (C::MAXT + 1));
     for (;;) {

@@ -15,15 +15,6 @@ namespace k2r {
 
 constexpr int MAX_SCAN_FIELDS = 16;  // 32-bit words per thread that scan<>/reduce<> can combine
 
-// a * b for operands below 2^24 (one full-rate instruction on the card)
-K2R_HD uint32_t mul24(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(a, b);
-#else
-    return a * b;
-#endif
-}
-
 #if defined(__HIPCC__)
 
 template <class SH, class TR, int NT>
@@ -54,14 +45,6 @@ struct GpuExec {
         f(tid, r);
     }
     __device__ __forceinline__ void barrier() { lds_barrier(); }
-    // A phase for the first wave only, ordered against its own earlier / later LDS traffic but with no workgroup barrier:
-    // the LDS executes one wave's instructions in order, so a chain of such phases hands data from lane to lane safely.
-    // The caller closes the chain with barrier().
-    template <class F>
-    __device__ __forceinline__ void par_wave0(F&& f) {
-        if (tid < 64) f(tid, r);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     // diagnostic builds only: attribute the cycles since the previous stamp to phase k (thread 0's view)
     __device__ __forceinline__ void stamp(int k) {
 #ifdef K2R_PROFILE
@@ -199,21 +182,6 @@ struct GpuExec {
     }
 
 
-    // Slots for a whole wave with ONE LDS atomic: every lane asks for v >= 0 units (several counters may share the word
-    // as bit fields); a wave scan gives each lane its offset, one lane adds the wave's total to *ctr.  Returns the lane's
-    // first unit.  All lanes of the wave must call it together.
-    __device__ __forceinline__ uint32_t wave_alloc(uint32_t* ctr, uint32_t v) {
-        constexpr int W = NT < 64 ? NT : 64;
-        const uint32_t incl = wave_incl_scan(v);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, W - 1);
-        // (spelled out: handed an atomicAdd, the compiler's atomic optimizer wraps it in its own lane bookkeeping)
-        const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)ctr;
-        uint32_t base = 0;
-        if ((tid & 63) == 0)
-            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(total) : "memory");
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        return base + incl - v;
-    }
     __device__ __forceinline__ uint32_t lds_or_nr(uint32_t* p, uint32_t v) { atomicOr(p, v); return 0; }
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
@@ -279,10 +247,6 @@ struct SimExec {
         for (int t = 0; t < NT; t++) f(t, regs[t]);
     }
     void barrier() {}
-    template <class F>
-    void par_wave0(F&& f) {
-        for (int t = 0; t < (NT < 64 ? NT : 64); t++) f(t, regs[t]);
-    }
     void barrier_global() {}
     void stamp(int) {}
     template <class T>
@@ -308,11 +272,6 @@ struct SimExec {
     }
 
 
-    uint32_t wave_alloc(uint32_t* ctr, uint32_t v) {  // (threads run one after the other: the counter is the prefix)
-        const uint32_t o = *ctr;
-        *ctr = o + v;
-        return o;
-    }
     uint32_t lds_or_nr(uint32_t* p, uint32_t v) {
         *p |= v;
         return 0;

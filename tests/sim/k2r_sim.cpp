@@ -19,7 +19,7 @@ static void run(const TileArgs& ta, TileResult* res) {
     SimExec<EncShared<C>, EncRegs, C::NT> ex(*sh);
     std::memset((void*)ex.regs.data(), 0x5A, ex.regs.size() * sizeof(EncRegs));  // registers start as garbage on a GPU
     std::vector<uint64_t> listV(C::MAXV + 1), listM(C::MAXT + 1);
-    std::vector<uint32_t> scmp(SCMP_WORDS * C::NT, 0xA5A5A5A5u);
+    std::vector<uint32_t> scmp(32 * C::NT, 0xA5A5A5A5u);
     encode_chunk<C, PADDED, VEC>(ex, ta, res, listV.data(), listM.data(), scmp.data());
 }
 
