@@ -21,6 +21,10 @@ struct dcdf_chunk {
     uint32_t fbits = 0;
     size_t len = 0;
     DevBuf d_bytes, d_descs;
+    // per instant: a single-node UNIFORM log over a multi-node snapshot.  The reference's search (log.rs:519-702) never reads
+    // eqB[0] and descends the snapshot with the log's (min, max) pair as if it were "equal": its result there is not the set of
+    // cells in range, so such instants are searched by the per-thread replica of that descent, not by the decoding wave walk.
+    std::vector<uint8_t> search_quirk;
 };
 
 namespace k2r {
@@ -128,6 +132,14 @@ k_fill_window(const ChunkRef* __restrict__ chunks, const WinQuery* __restrict__ 
 }
 
 
+// one (query, instant) of a search: its window bitmap
+struct SearchItem {
+    uint32_t query, instant;  // instant is absolute within the chunk
+    uint64_t bits_off;        // u32 words: the item's window bitmap, row-major over the query window (per-thread descent)
+    uint32_t w0, ncb;         // wave walk: first of the item's sub-window bitmaps (32 words each, [row block][column block]) and
+                              // column blocks per row block; w0 == SI_FLAT: the flat bitmap above is the one in use
+};
+constexpr uint32_t SI_FLAT = 0xffffffffu;
 // ---- wave-cooperative window decode ---------------------------------------------------------------------------------------
 // fill_window the MI355X way: one WAVE per (query, instant, sub-window of at most 32 x 32 cells) walks the nodes that
 // cover the sub-window ONCE, level by level (snapshot.rs:237-301, log.rs:349-508 are depth-first recursions over the same
@@ -491,14 +503,24 @@ struct WaveQ2 {
     uint32_t it[WQ2_CAP], is[WQ2_CAP], org[WQ2_CAP];
     int64_t mt[WQ2_CAP], ms[WQ2_CAP];
 };
-// MW = waves per SIMD the register allocator must leave room for; DENSE64: the batched form's output (int64, unit column stride)
-template <int MW, bool DENSE64>
+// What a search item adds to its WinItem (search = the same walk; instead of storing a cell it tests lower <= v <= upper and
+// sets the cell's bit in the sub-window's own 32-word bitmap -- word = row - top, bit = column - left -- at out[item * 32];
+// no two waves share a word, so there is nothing atomic about it and nothing to clear beforehand).
+struct SearchExtra {
+    int64_t lower, upper;
+};
+// MW = waves per SIMD the register allocator must leave room for; DENSE64: the batched form's output (int64, unit column stride);
+// SEARCH: mark matches (out = the bitmaps, sx = one SearchExtra per item) instead of storing values
+template <int MW, bool DENSE64, bool SEARCH = false>
 __global__ void __launch_bounds__(256, MW)
-k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ items, uint32_t n_items, void* out, int32_t out_dtype) {
+k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ items, uint32_t n_items, void* out, int32_t out_dtype,
+               const SearchExtra* __restrict__ sx = nullptr) {
     __shared__ WaveQ2 wq[4];
+    __shared__ uint32_t wbits[4][32];  // SEARCH: the sub-window's matches, one word per row (bit = column - wleft)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveQ2& q = wq[wave];
+    uint32_t* const rowbits = wbits[wave];
     for (uint32_t item = blockIdx.x * 4u + (uint32_t)wave; item < n_items; item += gridDim.x * 4u) {
         const WinItem I = items[item];
         const ChunkRef C = chunks[I.chunk];
@@ -513,12 +535,36 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
         const uint32_t sidelen0 = gD->sidelen;
         const uint32_t wtop = I.top, wbot = I.bottom, wleft = I.left, wright = I.right, osr = I.out_sr;
         const int64_t obase = (int64_t)I.out_off - (int64_t)wtop * osr - (int64_t)wleft;  // element offset of chunk cell (0, 0)
+        int64_t s_lo = 0, s_hi = 0;
+        if (SEARCH) {
+            s_lo = sx[item].lower;
+            s_hi = sx[item].upper;
+            if (lane < 32) rowbits[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
         auto put = [&](uint32_t r, uint32_t c, int64_t v) {
+            if (SEARCH) {
+                if (s_lo <= v && v <= s_hi) atomicOr(&rowbits[r - wtop], 1u << (c - wleft));
+                return;
+            }
             const int64_t off = obase + (int64_t)(r * osr + c);
             if (DENSE64) ((int64_t*)out)[off] = v;
             else store_typed(out, off, out_dtype, v, C.fbits);
         };
+        auto flush_bits = [&]() {
+            if (!SEARCH) return;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) ((uint32_t*)out)[(uint64_t)item * 32u + (uint32_t)lane] = rowbits[lane];  // (rows beyond the sub-window: 0)
+            __builtin_amdgcn_wave_barrier();
+        };
         auto fill_wave = [&](uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int64_t v) {
+            if (SEARCH) {  // (v is wave-uniform) a rectangle of one value: whole row segments at once
+                if (s_lo <= v && v <= s_hi && (uint32_t)lane < r1 - r0 && c1 > c0) {
+                    const uint32_t w1 = c1 - c0;
+                    atomicOr(&rowbits[r0 - wtop + (uint32_t)lane], (w1 >= 32u ? 0xffffffffu : ((1u << w1) - 1u)) << (c0 - wleft));
+                }
+                return;
+            }
             const uint32_t w = c1 - c0, area = (r1 - r0) * w;      // w <= 32, area <= 1024
             const uint32_t inv = (65536u + w - 1) / w;             // i / w == (i * inv) >> 16 for i < 2048
             for (uint32_t i = (uint32_t)lane; i < area; i += 64) {
@@ -532,6 +578,7 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
         const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
         if (all_one) {
             fill_wave(wtop, wbot, wleft, wright, max_t0 + max_s0);
+            flush_bits();
             continue;
         }
         if (lane == 0) {
@@ -623,8 +670,27 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
                 }
             }
         }
+        flush_bits();
         __builtin_amdgcn_wave_barrier();
     }
+}
+// counts of the (query, instant) items the wave walk marked: one thread each over the item's sub-window bitmaps
+__global__ void __launch_bounds__(64)
+k_search_count(const uint32_t* __restrict__ wbits, const SearchItem* __restrict__ items, const WinQuery* __restrict__ qs, uint32_t n,
+               uint32_t* __restrict__ counts) {
+    const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= n) return;
+    const SearchItem I = items[it];
+    if (I.w0 == SI_FLAT) return;  // (counted by k_search_mark)
+    const WinQuery Q = qs[I.query];
+    const uint32_t nrb = ((Q.bottom + 31u) >> 5) - (Q.top >> 5);
+    const uint4* w = (const uint4*)(wbits + (uint64_t)I.w0 * 32u);
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < nrb * I.ncb * 8u; i++) {
+        const uint4 x = w[i];
+        cnt += popc32(x.x) + popc32(x.y) + popc32(x.z) + popc32(x.w);
+    }
+    counts[it] = cnt;
 }
 
 // get / fill_cell: one thread per (query) point
@@ -642,16 +708,13 @@ k_get(const ChunkRef* __restrict__ chunks, const PointQuery* __restrict__ qs, ui
 
 // search pass 1: one thread per (query, instant) item runs the reference's pruned DFS and marks matches
 // in its private window bitmap.
-struct SearchItem {
-    uint32_t query, instant;  // instant is absolute within the chunk
-    uint64_t bits_off;        // u32 words
-};
 __global__ void __launch_bounds__(64)
 k_search_mark(const ChunkRef* __restrict__ chunks, const WinQuery* __restrict__ qs, const SearchItem* __restrict__ items,
               uint32_t n_items, uint32_t* __restrict__ bits, uint32_t* __restrict__ counts) {
     const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= n_items) return;
     const SearchItem I = items[it];
+    if (I.w0 != SI_FLAT) return;  // (marked by the wave walk)
     const WinQuery Q = qs[I.query];
     const ChunkRef C = chunks[Q.chunk];
     WinMark wm{bits + I.bits_off, Q.top, Q.left, Q.right - Q.left};
@@ -664,7 +727,8 @@ k_search_mark(const ChunkRef* __restrict__ chunks, const WinQuery* __restrict__ 
 // search pass 2: expand the bitmaps into sorted (instant,row,col) triples
 __global__ void __launch_bounds__(64)
 k_search_emit(const WinQuery* __restrict__ qs, const SearchItem* __restrict__ items, uint32_t n_items,
-              const uint32_t* __restrict__ bits, const uint64_t* __restrict__ offs, uint32_t* __restrict__ out) {
+              const uint32_t* __restrict__ bits, const uint32_t* __restrict__ wbits, const uint64_t* __restrict__ offs,
+              uint32_t* __restrict__ out) {
     const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= n_items) return;
     const SearchItem I = items[it];
@@ -672,6 +736,25 @@ k_search_emit(const WinQuery* __restrict__ qs, const SearchItem* __restrict__ it
     const uint32_t wc = Q.right - Q.left, nbits = (Q.bottom - Q.top) * wc;
     const uint32_t* bw = bits + I.bits_off;
     uint32_t* o = out + 3 * offs[it];
+    if (I.w0 != SI_FLAT) {  // sub-window bitmaps of the wave walk: rows in order, column blocks left to right
+        const uint32_t rb0 = Q.top >> 5, cb0 = Q.left >> 5;
+        for (uint32_t r = Q.top; r < Q.bottom; r++) {
+            const uint32_t rb = (r >> 5) - rb0, sub_top = rb == 0 ? Q.top : (r & ~31u);
+            for (uint32_t cb = 0; cb < I.ncb; cb++) {
+                uint32_t x = wbits[((uint64_t)I.w0 + rb * I.ncb + cb) * 32u + (r - sub_top)];
+                const uint32_t sub_left = cb == 0 ? Q.left : ((cb0 + cb) << 5);
+                while (x) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(x);
+                    x &= x - 1;
+                    o[0] = I.instant;
+                    o[1] = r;
+                    o[2] = sub_left + j;
+                    o += 3;
+                }
+            }
+        }
+        return;
+    }
     for (uint32_t w = 0; w < (nbits + 31) / 32; w++) {
         uint32_t x = bw[w];
         while (x) {
@@ -758,6 +841,11 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
             d.sidelen < std::max(d.rows, d.cols))
             return DCDF_ERR_FORMAT;
     c->len = len;
+    c->search_quirk.assign(c->descs.size(), 0);
+    for (size_t i = 0; i < c->descs.size(); i++) {
+        const InstDesc& L = c->descs[i];
+        if (L.is_log && !bmd_get(bytes, L.T, 0) && !bmd_get(bytes, L.E, 0) && bmd_get(bytes, c->descs[L.snap].T, 0)) c->search_quirk[i] = 1;
+    }
     K2R_HIP(c->d_bytes.alloc(len + 64));  // (slack: the wave decoder reads whole 16-byte blocks / 4-byte groups at the tail)
     K2R_HIP(hipMemcpy(c->d_bytes.p, bytes, len, hipMemcpyHostToDevice));
     K2R_HIP(c->d_descs.alloc(c->descs.size() * sizeof(InstDesc)));
@@ -950,7 +1038,15 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     dedup_chunks(chunks, nq, cidx, uniq);
     std::vector<WinQuery> qs(nq);
     std::vector<SearchItem> items;
+    // k = 2 chunks: the wave-cooperative walk of fill_window marks the matches (one wave per 32 x 32 sub-window and
+    // instant, each into its own 32-word bitmap); other arities -- and the instants of dcdf_chunk::search_quirk -- keep the
+    // per-thread pruned descent and its flat per-item bitmap
+    bool node_wise = std::getenv("K2R_SEARCH_DFS") == nullptr;  // (diagnostics: A/B against the per-thread descent)
+    for (const dcdf_chunk* u : uniq) node_wise = node_wise && node_kernel_ok(u);
+    std::vector<WinItem> witems;
+    std::vector<SearchExtra> sx;
     uint64_t bits_words = 0;
+    size_t n_dfs = 0;
     for (size_t q = 0; q < nq; q++) {
         if (!chunks[q]) return DCDF_ERR_BAD_ARG;
         const dcdf_cube c = norm_cube(cubes[q]);
@@ -963,15 +1059,34 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         Q.upper = std::max(lower[q], upper[q]);
         const uint64_t cells = (uint64_t)(c.bottom - c.top) * (c.right - c.left);
         if (cells == 0) continue;
+        const uint32_t ncb = ((c.right + 31u) >> 5) - (c.left >> 5);
         for (uint32_t i = c.start; i < c.end; i++) {
-            items.push_back(SearchItem{(uint32_t)q, i, bits_words});
-            bits_words += (cells + 31) / 32;
+            if (node_wise && !chunks[q]->search_quirk[i]) {
+                if (witems.size() + 4096 > 0xffffff00u) return DCDF_ERR_CAPACITY;
+                items.push_back(SearchItem{(uint32_t)q, i, 0, (uint32_t)witems.size(), ncb});
+                for (uint32_t r = c.top & ~31u; r < c.bottom; r += 32)
+                    for (uint32_t cc = c.left & ~31u; cc < c.right; cc += 32) {
+                        WinItem it{};
+                        it.chunk = Q.chunk;
+                        it.inst = i;
+                        it.top = (uint16_t)std::max(r, c.top);
+                        it.bottom = (uint16_t)std::min(r + 32, c.bottom);
+                        it.left = (uint16_t)std::max(cc, c.left);
+                        it.right = (uint16_t)std::min(cc + 32, c.right);
+                        witems.push_back(it);
+                        sx.push_back(SearchExtra{Q.lower, Q.upper});
+                    }
+            } else {
+                items.push_back(SearchItem{(uint32_t)q, i, bits_words, SI_FLAT, 0});
+                bits_words += (cells + 31) / 32;
+                n_dfs++;
+            }
         }
     }
     for (size_t q = 0; q < nq; q++) counts[q] = 0;
     float ms_total = 0.f;
     std::vector<uint32_t> item_counts(items.size());
-    DevBuf d_refs, d_qs, d_items, d_bits, d_counts, d_offs, d_out;
+    DevBuf d_refs, d_qs, d_items, d_bits, d_wbits, d_witems, d_sx, d_counts, d_offs, d_out;
     if (!items.empty()) {
         int rc = upload_refs(chunks, cidx, uniq.size(), uniq, d_refs);
         if (rc != DCDF_OK) return rc;
@@ -979,16 +1094,33 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         K2R_HIP(hipMemcpy(d_qs.p, qs.data(), nq * sizeof(WinQuery), hipMemcpyHostToDevice));
         K2R_HIP(d_items.alloc(items.size() * sizeof(SearchItem)));
         K2R_HIP(hipMemcpy(d_items.p, items.data(), items.size() * sizeof(SearchItem), hipMemcpyHostToDevice));
-        K2R_HIP(d_bits.alloc(bits_words * 4));
-        K2R_HIP(hipMemset(d_bits.p, 0, bits_words * 4));
+        if (n_dfs) {
+            K2R_HIP(d_bits.alloc(std::max<uint64_t>(bits_words, 1) * 4));
+            K2R_HIP(hipMemset(d_bits.p, 0, std::max<uint64_t>(bits_words, 1) * 4));
+        }
+        const uint32_t nw = (uint32_t)witems.size();
+        if (nw) {
+            K2R_HIP(d_witems.alloc(witems.size() * sizeof(WinItem)));
+            K2R_HIP(hipMemcpy(d_witems.p, witems.data(), witems.size() * sizeof(WinItem), hipMemcpyHostToDevice));
+            K2R_HIP(d_sx.alloc(sx.size() * sizeof(SearchExtra)));
+            K2R_HIP(hipMemcpy(d_sx.p, sx.data(), sx.size() * sizeof(SearchExtra), hipMemcpyHostToDevice));
+            K2R_HIP(d_wbits.alloc((size_t)nw * 128));  // (every word is written by the walk: nothing to clear)
+        }
         K2R_HIP(d_counts.alloc(items.size() * 4));
         EventPair ev;
         K2R_HIP(ev.create());
         const hipEvent_t e0 = ev.e0, e1 = ev.e1;
         const uint32_t ni = (uint32_t)items.size();
         K2R_HIP(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_search_mark, dim3((ni + 63) / 64), dim3(64), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
-                           d_items.as<SearchItem>(), ni, d_bits.as<uint32_t>(), d_counts.as<uint32_t>());
+        if (nw) {
+            hipLaunchKernelGGL((k_window_wave2<4, false, true>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
+                               d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
+            hipLaunchKernelGGL(k_search_count, dim3((ni + 63) / 64), dim3(64), 0, 0, d_wbits.as<uint32_t>(), d_items.as<SearchItem>(),
+                               d_qs.as<WinQuery>(), ni, d_counts.as<uint32_t>());
+        }
+        if (n_dfs)
+            hipLaunchKernelGGL(k_search_mark, dim3((ni + 63) / 64), dim3(64), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
+                               d_items.as<SearchItem>(), ni, d_bits.as<uint32_t>(), d_counts.as<uint32_t>());
         K2R_HIP(hipEventRecord(e1, 0));
         K2R_HIP(hipGetLastError());
         K2R_HIP(hipMemcpy(item_counts.data(), d_counts.p, items.size() * 4, hipMemcpyDeviceToHost));
@@ -1015,7 +1147,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
             K2R_HIP(d_out.alloc(run * 12));
             K2R_HIP(hipEventRecord(e0, 0));
             hipLaunchKernelGGL(k_search_emit, dim3((ni + 63) / 64), dim3(64), 0, 0, d_qs.as<WinQuery>(),
-                               d_items.as<SearchItem>(), ni, d_bits.as<uint32_t>(), d_offs.as<uint64_t>(),
+                               d_items.as<SearchItem>(), ni, d_bits.as<uint32_t>(), d_wbits.as<uint32_t>(), d_offs.as<uint64_t>(),
                                d_out.as<uint32_t>());
             K2R_HIP(hipEventRecord(e1, 0));
             K2R_HIP(hipGetLastError());
