@@ -21,6 +21,10 @@ struct dcdf_chunk {
     uint32_t fbits = 0;
     size_t len = 0;
     DevBuf d_bytes, d_descs;
+    // k = 2, sidelen >= 64: for every instant the walk's state at each node of side 32 (k_top_table, built at open): the wave
+    // walks of fill_window / search start there instead of at the root (their items never leave one square of the 32-grid)
+    DevBuf d_top;
+    uint32_t top_g = 0;  // squares per side (sidelen / 32), 0 = no table
     // per instant: a single-node UNIFORM log over a multi-node snapshot.  The reference's search (log.rs:519-702) never reads
     // eqB[0] and descends the snapshot with the log's (min, max) pair as if it were "equal": its result there is not the set of
     // cells in range, so such instants are searched by the per-thread replica of that descent, not by the decoding wave walk.
@@ -41,10 +45,16 @@ struct EventPair {  // destroyed on every exit path
     }
 };
 
+struct TopEnt {  // the walk's state at one node (log.rs:360-361): both first-child indices NONE = its square has the one value mt + ms
+    uint32_t bt, bs;
+    int64_t mt, ms;
+};
 struct ChunkRef {  // device-visible handle of an opened chunk
     const uint8_t* bytes;
     const InstDesc* descs;
     uint32_t instants, rows, cols, fbits;
+    const TopEnt* top;  // [instant][top_g * top_g] or null
+    uint32_t top_g, _pad;
 };
 
 // ---- host-side parser (chunk.rs:247-266, block.rs:99-109, snapshot.rs:62-81, log.rs:68-89,
@@ -511,7 +521,7 @@ struct SearchExtra {
 };
 // MW = waves per SIMD the register allocator must leave room for; DENSE64: the batched form's output (int64, unit column stride);
 // SEARCH: mark matches (out = the bitmaps, sx = one SearchExtra per item) instead of storing values
-template <int MW, bool DENSE64, bool SEARCH = false>
+template <int MW, bool DENSE64, bool SEARCH = false, bool USE_TOP = true>
 __global__ void __launch_bounds__(256, MW)
 k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ items, uint32_t n_items, void* out, int32_t out_dtype,
                const SearchExtra* __restrict__ sx = nullptr) {
@@ -572,24 +582,44 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
                 put(r0 + rr, c0 + i - rr * w, v);
             }
         };
-        const bool single_s = !gbm_get(gb, S.T, 0);
-        const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
-        const int64_t max_s0 = dacd_get(b, SD.mx, 0), max_t0 = has_log ? dacd_get(b, D.mx, 0) : 0;
-        const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
-        if (all_one) {
-            fill_wave(wtop, wbot, wleft, wright, max_t0 + max_s0);
-            flush_bits();
-            continue;
-        }
-        if (lane == 0) {
-            q.it[0] = (has_log && !single_t) ? 1u : WQ_NONE;
-            q.is[0] = single_s ? WQ_NONE : 1u;
-            q.org[0] = 0;
-            q.mt[0] = max_t0;
-            q.ms[0] = max_s0;
+        uint32_t lo = 0, hi = 1, side = sidelen0;
+        if (USE_TOP && C.top) {  // start at the node of side 32 that holds the sub-window (k_top_table)
+            typedef __attribute__((address_space(1))) const TopEnt* gtop;
+            const gtop e = (gtop)C.top + ((size_t)I.inst * C.top_g + (wtop >> 5)) * C.top_g + (wleft >> 5);
+            const uint32_t ebt = e->bt, ebs = e->bs;
+            const int64_t emt = e->mt, ems = e->ms;
+            if (ebt == WQ_NONE && ebs == WQ_NONE) {
+                fill_wave(wtop, wbot, wleft, wright, emt + ems);
+                flush_bits();
+                continue;
+            }
+            if (lane == 0) {
+                q.it[0] = ebt;
+                q.is[0] = ebs;
+                q.org[0] = ((wtop & ~31u) << 16) | (wleft & ~31u);
+                q.mt[0] = emt;
+                q.ms[0] = ems;
+            }
+            side = 32;
+        } else {
+            const bool single_s = !gbm_get(gb, S.T, 0);
+            const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
+            const int64_t max_s0 = dacd_get(b, SD.mx, 0), max_t0 = has_log ? dacd_get(b, D.mx, 0) : 0;
+            const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
+            if (all_one) {
+                fill_wave(wtop, wbot, wleft, wright, max_t0 + max_s0);
+                flush_bits();
+                continue;
+            }
+            if (lane == 0) {
+                q.it[0] = (has_log && !single_t) ? 1u : WQ_NONE;
+                q.is[0] = single_s ? WQ_NONE : 1u;
+                q.org[0] = 0;
+                q.mt[0] = max_t0;
+                q.ms[0] = max_s0;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t lo = 0, hi = 1, side = sidelen0;
         while (side > 4) {  // lane = frontier node; children of side >= 4 go to the next frontier
             const uint32_t cs = side >> 1;
             uint32_t next = hi;
@@ -672,6 +702,76 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
         }
         flush_bits();
         __builtin_amdgcn_wave_barrier();
+    }
+}
+// The walk's state at every node of side 32, for every instant of one chunk (dcdf_chunk::d_top): one wave per instant walks
+// the top of the tree(s) breadth-first -- 1, 4, 16, ... nodes -- with the same expand4 as the query walks.
+__global__ void __launch_bounds__(64)
+k_top_table(ChunkRef C, TopEnt* __restrict__ table) {
+    __shared__ WaveQ2 q;
+    const int lane = threadIdx.x;
+    const uint32_t inst = blockIdx.x, G = C.top_g;
+    const uint8_t* const b = C.bytes;
+    const gbytes gb = (gbytes)C.bytes;
+    const gdesc gD = (gdesc)C.descs + inst;
+    const bool has_log = gD->is_log != 0;
+    const gdesc gS = has_log ? (gdesc)C.descs + gD->snap : gD;
+    const InstDesc& D = C.descs[inst];
+    const InstDesc& SD = has_log ? C.descs[gD->snap] : D;
+    const TreeRef S = tree_ref(gS), L = tree_ref(gD);
+    TopEnt* const out = table + (size_t)inst * G * G;
+    auto put_square = [&](uint32_t r, uint32_t c, uint32_t sd, const TopEnt& e) {  // every 32-square of the node at (r, c), side sd
+        const uint32_t n = sd >> 5;
+        for (uint32_t i = 0; i < n * n; i++) out[((r >> 5) + i / n) * G + (c >> 5) + i % n] = e;
+    };
+    const bool single_s = !gbm_get(gb, S.T, 0);
+    const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
+    const int64_t max_s0 = dacd_get(b, SD.mx, 0), max_t0 = has_log ? dacd_get(b, D.mx, 0) : 0;
+    const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
+    if (all_one) {
+        for (uint32_t i = (uint32_t)lane; i < G * G; i += 64) out[i] = TopEnt{WQ_NONE, WQ_NONE, max_t0, max_s0};
+        return;
+    }
+    if (lane == 0) {
+        q.it[0] = (has_log && !single_t) ? 1u : WQ_NONE;
+        q.is[0] = single_s ? WQ_NONE : 1u;
+        q.org[0] = 0;
+        q.mt[0] = max_t0;
+        q.ms[0] = max_s0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t lo = 0, hi = 1;
+    for (uint32_t side = gD->sidelen; side > 32; side >>= 1) {  // (at most 64 nodes of side 64 at the last step: one pass per level)
+        const uint32_t cs = side >> 1, n = lo + (uint32_t)lane;
+        const bool live = n < hi;
+        Kids kd;
+        kd.fill = 0;
+        uint32_t po = 0;
+        if (live) {
+            const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+            po = q.org[n];
+            expand4(gb, S, SD.mx, L, D.mx, p, &kd);
+        }
+        const uint32_t pushm = live ? (~kd.fill & 15u) : 0u, np = popc32(pushm);
+        const uint32_t inc = GpuExecScan::incl(np);
+        uint32_t pos = hi + inc - np;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (!live) continue;
+            const uint32_t cr = (po >> 16) + (uint32_t)(c >> 1) * cs, cc = (po & 0xffffu) + (uint32_t)(c & 1) * cs;
+            if ((kd.fill >> c) & 1u) {
+                put_square(cr, cc, cs, TopEnt{WQ_NONE, WQ_NONE, kd.st[c].mt, kd.st[c].ms});
+            } else if (cs == 32) {
+                put_square(cr, cc, 32, TopEnt{kd.st[c].bt, kd.st[c].bs, kd.st[c].mt, kd.st[c].ms});
+            } else {
+                q.it[pos] = kd.st[c].bt; q.is[pos] = kd.st[c].bs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = kd.st[c].mt; q.ms[pos] = kd.st[c].ms;
+                pos++;
+            }
+        }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        __builtin_amdgcn_wave_barrier();
+        lo = hi;
+        hi = cs == 32 ? hi : hi + tot;
     }
 }
 // counts of the (query, instant) items the wave walk marked: one thread each over the item's sub-window bitmaps
@@ -850,6 +950,15 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
     K2R_HIP(hipMemcpy(c->d_bytes.p, bytes, len, hipMemcpyHostToDevice));
     K2R_HIP(c->d_descs.alloc(c->descs.size() * sizeof(InstDesc)));
     K2R_HIP(hipMemcpy(c->d_descs.p, c->descs.data(), c->descs.size() * sizeof(InstDesc), hipMemcpyHostToDevice));
+    if (c->descs[0].k == 2 && c->descs[0].sidelen >= 64 && c->descs[0].sidelen <= 256 && !std::getenv("K2R_NO_TOP_TABLE")) {
+        const uint32_t g = c->descs[0].sidelen / 32;
+        K2R_HIP(c->d_top.alloc((size_t)c->instants * g * g * sizeof(TopEnt)));
+        ChunkRef ref{c->d_bytes.as<uint8_t>(), c->d_descs.as<InstDesc>(), c->instants, c->rows, c->cols, c->fbits, nullptr, g, 0};
+        hipLaunchKernelGGL(k_top_table, dim3(c->instants), dim3(64), 0, 0, ref, c->d_top.as<TopEnt>());
+        K2R_HIP(hipGetLastError());
+        K2R_HIP(hipDeviceSynchronize());
+        c->top_g = g;
+    }
     *h = c.release();
     return DCDF_OK;
 }
@@ -869,7 +978,8 @@ extern "C" int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* 
 }
 
 static ChunkRef make_ref(const dcdf_chunk* h) {
-    return ChunkRef{h->d_bytes.as<uint8_t>(), h->d_descs.as<InstDesc>(), h->instants, h->rows, h->cols, h->fbits};
+    return ChunkRef{h->d_bytes.as<uint8_t>(), h->d_descs.as<InstDesc>(), h->instants, h->rows, h->cols, h->fbits,
+                    h->top_g ? h->d_top.as<TopEnt>() : nullptr, h->top_g, 0};
 }
 // geom::Cube::new reorders reversed bounds (geom.rs:83-103)
 static dcdf_cube norm_cube(const dcdf_cube& c) {
