@@ -21,10 +21,11 @@ struct dcdf_chunk {
     uint32_t fbits = 0;
     size_t len = 0;
     DevBuf d_bytes, d_descs;
-    // k = 2, sidelen >= 64: for every instant the walk's state at each node of side 32 (k_top_table, built at open): the wave
-    // walks of fill_window / search start there instead of at the root (their items never leave one square of the 32-grid)
+    // k = 2, sidelen 32..256: for every instant the walk's state at each node of side 16 (k_top_table, built at open): the wave
+    // walks of fill_window / search start there instead of at the root (an item never leaves one square of the 32-grid: it
+    // begins with that square's four entries)
     DevBuf d_top;
-    uint32_t top_g = 0;  // squares per side (sidelen / 32), 0 = no table
+    uint32_t top_g = 0;  // squares per side (sidelen / 16), 0 = no table
     // per instant: a single-node UNIFORM log over a multi-node snapshot.  The reference's search (log.rs:519-702) never reads
     // eqB[0] and descends the snapshot with the log's (min, max) pair as if it were "equal": its result there is not the set of
     // cells in range, so such instants are searched by the per-thread replica of that descent, not by the decoding wave walk.
@@ -47,7 +48,7 @@ struct EventPair {  // destroyed on every exit path
 
 struct TopEnt {  // the walk's state at one node (log.rs:360-361): both first-child indices NONE = its square has the one value mt + ms
     uint32_t bt, bs;
-    int64_t mt, ms;
+    int32_t mt, ms;  // (a chunk with a value beyond int32 gets no table: k_top_table reports it)
 };
 struct ChunkRef {  // device-visible handle of an opened chunk
     const uint8_t* bytes;
@@ -583,24 +584,38 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
             }
         };
         uint32_t lo = 0, hi = 1, side = sidelen0;
-        if (USE_TOP && C.top) {  // start at the node of side 32 that holds the sub-window (k_top_table)
+        if (USE_TOP && C.top) {  // start at the (up to four) nodes of side 16 that hold the sub-window (k_top_table)
             typedef __attribute__((address_space(1))) const TopEnt* gtop;
-            const gtop e = (gtop)C.top + ((size_t)I.inst * C.top_g + (wtop >> 5)) * C.top_g + (wleft >> 5);
-            const uint32_t ebt = e->bt, ebs = e->bs;
-            const int64_t emt = e->mt, ems = e->ms;
-            if (ebt == WQ_NONE && ebs == WQ_NONE) {
-                fill_wave(wtop, wbot, wleft, wright, emt + ems);
+            const uint32_t cr = (wtop & ~31u) + (uint32_t)((lane >> 1) & 1) * 16u, cc = (wleft & ~31u) + (uint32_t)(lane & 1) * 16u;
+            const bool mine = lane < 4 && cr < wbot && cr + 16 > wtop && cc < wright && cc + 16 > wleft;
+            uint32_t ebt = WQ_NONE, ebs = WQ_NONE;
+            int64_t emt = 0, ems = 0;
+            if (mine) {
+                const gtop e = (gtop)C.top + ((size_t)I.inst * C.top_g + (cr >> 4)) * C.top_g + (cc >> 4);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 x = *(__attribute__((address_space(1))) const u32x4*)e;
+                ebt = x.x; ebs = x.y; emt = (int32_t)x.z; ems = (int32_t)x.w;
+            }
+            const bool isfill = mine && ebt == WQ_NONE && ebs == WQ_NONE, push = mine && !isfill;
+            const unsigned long long bp = __builtin_amdgcn_ballot_w64(push);
+            if (push) {
+                const uint32_t pos = __builtin_amdgcn_mbcnt_lo((uint32_t)bp, 0u);
+                q.it[pos] = ebt; q.is[pos] = ebs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = emt; q.ms[pos] = ems;
+            }
+            unsigned long long bf = __builtin_amdgcn_ballot_w64(isfill);
+            while (bf) {  // squares of one value: their part of the sub-window, by the whole wave
+                const int l = __builtin_ctzll(bf);
+                bf &= bf - 1;
+                const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)cr, l), ccl = (uint32_t)__builtin_amdgcn_readlane((int)cc, l);
+                const int64_t v = (int64_t)__builtin_amdgcn_readlane((int)(int32_t)emt, l) + (int64_t)__builtin_amdgcn_readlane((int)(int32_t)ems, l);
+                fill_wave(rr > wtop ? rr : wtop, rr + 16 < wbot ? rr + 16 : wbot, ccl > wleft ? ccl : wleft, ccl + 16 < wright ? ccl + 16 : wright, v);
+            }
+            hi = (uint32_t)__builtin_popcountll(bp);
+            side = 16;
+            if (hi == 0) {
                 flush_bits();
                 continue;
             }
-            if (lane == 0) {
-                q.it[0] = ebt;
-                q.is[0] = ebs;
-                q.org[0] = ((wtop & ~31u) << 16) | (wleft & ~31u);
-                q.mt[0] = emt;
-                q.ms[0] = ems;
-            }
-            side = 32;
         } else {
             const bool single_s = !gbm_get(gb, S.T, 0);
             const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
@@ -674,6 +689,9 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
             side = cs;
         }
         // ---- nodes of side 4: the lane finishes its 16 cells ----
+#ifdef K2R_DIAG_NO_FINAL
+        hi = lo;  // (diagnostic build: time of the upper levels alone; results are wrong)
+#endif
         for (uint32_t base = lo; base < hi; base += 64) {
             const uint32_t n = base + (uint32_t)lane;
             if (n >= hi) continue;
@@ -707,7 +725,7 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
 // The walk's state at every node of side 32, for every instant of one chunk (dcdf_chunk::d_top): one wave per instant walks
 // the top of the tree(s) breadth-first -- 1, 4, 16, ... nodes -- with the same expand4 as the query walks.
 __global__ void __launch_bounds__(64)
-k_top_table(ChunkRef C, TopEnt* __restrict__ table) {
+k_top_table(ChunkRef C, TopEnt* __restrict__ table, uint32_t* __restrict__ overflow) {
     __shared__ WaveQ2 q;
     const int lane = threadIdx.x;
     const uint32_t inst = blockIdx.x, G = C.top_g;
@@ -720,16 +738,18 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table) {
     const InstDesc& SD = has_log ? C.descs[gD->snap] : D;
     const TreeRef S = tree_ref(gS), L = tree_ref(gD);
     TopEnt* const out = table + (size_t)inst * G * G;
-    auto put_square = [&](uint32_t r, uint32_t c, uint32_t sd, const TopEnt& e) {  // every 32-square of the node at (r, c), side sd
-        const uint32_t n = sd >> 5;
-        for (uint32_t i = 0; i < n * n; i++) out[((r >> 5) + i / n) * G + (c >> 5) + i % n] = e;
+    auto put_square = [&](uint32_t r, uint32_t c, uint32_t sd, uint32_t bt, uint32_t bs, int64_t mt, int64_t ms) {  // every 16-square of the node
+        if (mt != (int32_t)mt || ms != (int32_t)ms) *overflow = 1;
+        const TopEnt e{bt, bs, (int32_t)mt, (int32_t)ms};
+        const uint32_t n = sd >> 4;
+        for (uint32_t i = 0; i < n * n; i++) out[((r >> 4) + i / n) * G + (c >> 4) + i % n] = e;
     };
     const bool single_s = !gbm_get(gb, S.T, 0);
     const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
     const int64_t max_s0 = dacd_get(b, SD.mx, 0), max_t0 = has_log ? dacd_get(b, D.mx, 0) : 0;
     const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
     if (all_one) {
-        for (uint32_t i = (uint32_t)lane; i < G * G; i += 64) out[i] = TopEnt{WQ_NONE, WQ_NONE, max_t0, max_s0};
+        if (lane == 0) put_square(0, 0, G * 16, WQ_NONE, WQ_NONE, max_t0, max_s0);
         return;
     }
     if (lane == 0) {
@@ -741,7 +761,7 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table) {
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t lo = 0, hi = 1;
-    for (uint32_t side = gD->sidelen; side > 32; side >>= 1) {  // (at most 64 nodes of side 64 at the last step: one pass per level)
+    for (uint32_t side = gD->sidelen; side > 16; side >>= 1) {  // (at most 64 nodes of side 32 at the last step: one pass per level)
         const uint32_t cs = side >> 1, n = lo + (uint32_t)lane;
         const bool live = n < hi;
         Kids kd;
@@ -760,9 +780,9 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table) {
             if (!live) continue;
             const uint32_t cr = (po >> 16) + (uint32_t)(c >> 1) * cs, cc = (po & 0xffffu) + (uint32_t)(c & 1) * cs;
             if ((kd.fill >> c) & 1u) {
-                put_square(cr, cc, cs, TopEnt{WQ_NONE, WQ_NONE, kd.st[c].mt, kd.st[c].ms});
-            } else if (cs == 32) {
-                put_square(cr, cc, 32, TopEnt{kd.st[c].bt, kd.st[c].bs, kd.st[c].mt, kd.st[c].ms});
+                put_square(cr, cc, cs, WQ_NONE, WQ_NONE, kd.st[c].mt, kd.st[c].ms);
+            } else if (cs == 16) {
+                put_square(cr, cc, 16, kd.st[c].bt, kd.st[c].bs, kd.st[c].mt, kd.st[c].ms);
             } else {
                 q.it[pos] = kd.st[c].bt; q.is[pos] = kd.st[c].bs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = kd.st[c].mt; q.ms[pos] = kd.st[c].ms;
                 pos++;
@@ -771,7 +791,7 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table) {
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         __builtin_amdgcn_wave_barrier();
         lo = hi;
-        hi = cs == 32 ? hi : hi + tot;
+        hi = cs == 16 ? hi : hi + tot;
     }
 }
 // counts of the (query, instant) items the wave walk marked: one thread each over the item's sub-window bitmaps
@@ -950,14 +970,18 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
     K2R_HIP(hipMemcpy(c->d_bytes.p, bytes, len, hipMemcpyHostToDevice));
     K2R_HIP(c->d_descs.alloc(c->descs.size() * sizeof(InstDesc)));
     K2R_HIP(hipMemcpy(c->d_descs.p, c->descs.data(), c->descs.size() * sizeof(InstDesc), hipMemcpyHostToDevice));
-    if (c->descs[0].k == 2 && c->descs[0].sidelen >= 64 && c->descs[0].sidelen <= 256 && !std::getenv("K2R_NO_TOP_TABLE")) {
-        const uint32_t g = c->descs[0].sidelen / 32;
-        K2R_HIP(c->d_top.alloc((size_t)c->instants * g * g * sizeof(TopEnt)));
+    if (c->descs[0].k == 2 && c->descs[0].sidelen >= 32 && c->descs[0].sidelen <= 256 && !std::getenv("K2R_NO_TOP_TABLE")) {
+        const uint32_t g = c->descs[0].sidelen / 16;
+        const size_t tbytes = (size_t)c->instants * g * g * sizeof(TopEnt);
+        K2R_HIP(c->d_top.alloc(tbytes + 4));  // (+ the "a value does not fit int32" word)
+        uint32_t* const d_ovf = (uint32_t*)(c->d_top.as<uint8_t>() + tbytes);
+        K2R_HIP(hipMemset(d_ovf, 0, 4));
         ChunkRef ref{c->d_bytes.as<uint8_t>(), c->d_descs.as<InstDesc>(), c->instants, c->rows, c->cols, c->fbits, nullptr, g, 0};
-        hipLaunchKernelGGL(k_top_table, dim3(c->instants), dim3(64), 0, 0, ref, c->d_top.as<TopEnt>());
+        hipLaunchKernelGGL(k_top_table, dim3(c->instants), dim3(64), 0, 0, ref, c->d_top.as<TopEnt>(), d_ovf);
         K2R_HIP(hipGetLastError());
-        K2R_HIP(hipDeviceSynchronize());
-        c->top_g = g;
+        uint32_t ovf = 0;
+        K2R_HIP(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
+        if (!ovf) c->top_g = g;
     }
     *h = c.release();
     return DCDF_OK;
