@@ -711,6 +711,14 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = g.val[e];
                 }
+                if (DENSE64 && !SEARCH && inside) {  // two cells of a row per store (16 bytes, any 8-byte alignment)
+                    typedef long long ll2 __attribute__((ext_vector_type(2)));
+                    typedef ll2 __attribute__((aligned(8))) ll2u;
+                    int64_t* const o0 = (int64_t*)out + (obase + (int64_t)(cr * osr + cc));
+                    *(__attribute__((address_space(1))) ll2u*)o0 = ll2{v[0], v[1]};
+                    *(__attribute__((address_space(1))) ll2u*)(o0 + osr) = ll2{v[2], v[3]};
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const uint32_t r = cr + (uint32_t)(e >> 1), cl = cc + (uint32_t)(e & 1);
