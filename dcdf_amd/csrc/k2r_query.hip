@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "k2r_decode.h"
@@ -26,6 +27,10 @@ struct dcdf_chunk {
     // begins with that square's four entries)
     DevBuf d_top;
     uint32_t top_g = 0;  // squares per side (sidelen / 16), 0 = no table
+    // every stored value of every instant lies in [-2^30, 2^30) (from the root extremes): the query walks then run on 32-bit
+    // values (NodeStT<int32_t>).  (A crafted chunk whose inner Dac values contradict its roots decodes to different garbage than
+    // with 64-bit arithmetic; no address depends on a value.)
+    bool narrow32 = false;
     // per instant: a single-node UNIFORM log over a multi-node snapshot.  The reference's search (log.rs:519-702) never reads
     // eqB[0] and descends the snapshot with the log's (min, max) pair as if it were "equal": its result there is not the set of
     // cells in range, so such instants are searched by the per-thread replica of that descent, not by the decoding wave walk.
@@ -181,10 +186,14 @@ struct GpuExecScan {  // inclusive prefix sum over the 64 lanes (DPP), as GpuExe
         return (uint32_t)x;
     }
 };
-struct NodeSt {
+// V = int64_t in general; int32_t for chunks whose stored values all lie in [-2^30, 2^30) (dcdf_chunk::narrow32: every node
+// extreme and every log difference then fits 32 bits), which halves the walk's arithmetic and its register footprint
+template <class V>
+struct NodeStT {
     uint32_t bt, bs;  // index of the node's FIRST CHILD in the log / snapshot tree (1 + rank(T, node) * k^2), or NONE
-    int64_t mt, ms;   // log.rs:360-361 max_t, max_s
+    V mt, ms;         // log.rs:360-361 max_t, max_s
 };
+typedef NodeStT<int64_t> NodeSt;
 // One step of the synchronized descent (log.rs:392-505; snapshot.rs:281-299 when there is no log): child c of a node.
 // Returns true when the child's whole square has one value (*val), else the child's state in *o.  The rank that locates
 // the child's own children is computed HERE, next to the child's other loads (they are independent of each other), so that
@@ -434,7 +443,9 @@ __device__ __forceinline__ TreeRef tree_ref(const InstDesc& d) {
 }
 // the four Lmax values at index i .. i+3 (those at or beyond the Dac's length: 0); `full` = the whole Dac, for values of
 // three or more bytes (rare)
-__device__ __forceinline__ void dac4(gbytes b, const TreeRef& t, const DacDesc& full, uint32_t i, int64_t (&out)[4]) {
+template <class V>
+__device__ __forceinline__ void dac4(gbytes b, const TreeRef& t, const DacDesc& full, uint32_t i, V (&out)[4]) {
+    typedef typename std::conditional<sizeof(V) == 4, uint32_t, uint64_t>::type U;
     const uint32_t len = t.c0.len;
     const uint32_t b0 = gld32(b + t.by0 + i);
     uint32_t cb = 0, r0 = 0;
@@ -445,30 +456,33 @@ __device__ __forceinline__ void dac4(gbytes b, const TreeRef& t, const DacDesc& 
     uint32_t q = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        uint64_t n = (b0 >> (8 * c)) & 0xffu;
+        U n = (b0 >> (8 * c)) & 0xffu;
         const bool more = (cb >> (3 - c)) & 1u;
         if (more) {
             if ((cb1 >> (3 - q)) & 1u) {  // three or more bytes: the general walk
-                out[c] = i + c < len ? dacd_get((const uint8_t*)b, full, i + c) : 0;
+                out[c] = i + c < len ? (V)dacd_get((const uint8_t*)b, full, i + c) : (V)0;
                 q++;
                 continue;
             }
-            n |= (uint64_t)((b1 >> (8 * q)) & 0xffu) << 8;
+            n |= (U)((b1 >> (8 * q)) & 0xffu) << 8;
             q++;
         }
-        out[c] = i + c < len ? (int64_t)((n >> 1) ^ (0 - (n & 1))) : 0;
+        out[c] = i + c < len ? (V)((n >> 1) ^ ((U)0 - (n & 1))) : (V)0;
     }
 }
-struct Kids {
-    NodeSt st[4];
-    int64_t val[4];
+template <class V>
+struct KidsT {
+    NodeStT<V> st[4];
+    V val[4];
     uint32_t fill;  // bit c: child c's whole square has the single value val[c]
 };
+typedef KidsT<int64_t> Kids;
 // the four children of node p (log.rs:392-505 / snapshot.rs:281-299 for all of i, j at once)
+template <class V>
 __device__ __forceinline__ void expand4(gbytes b, const TreeRef& S, const DacDesc& Sfull, const TreeRef& L, const DacDesc& Lfull,
-                                        const NodeSt& p, Kids* o) {
+                                        const NodeStT<V>& p, KidsT<V>* o) {
     const bool has_t = p.bt != WQ_NONE, has_s = p.bs != WQ_NONE;
-    int64_t vt[4] = {p.mt, p.mt, p.mt, p.mt}, vs[4] = {0, 0, 0, 0};
+    V vt[4] = {p.mt, p.mt, p.mt, p.mt}, vs[4] = {0, 0, 0, 0};
     uint32_t tt = 0, ts = 0, rt = 0, rs = 0;  // T nibbles (bit c = 8 >> c) and rank of the first child
     bool cells_t = true, cells_s = true;      // the children are beyond T: cells
     if (has_t) {
@@ -487,9 +501,9 @@ __device__ __forceinline__ void expand4(gbytes b, const TreeRef& S, const DacDes
         const bool bit_t = (tt >> (3 - c)) & 1u, bit_s = (ts >> (3 - c)) & 1u;
         const bool leaf_t = !has_t || cells_t || !bit_t, leaf_s = !has_s || cells_s || !bit_s;
         const uint32_t rtc = rt + popc32(tt >> (4 - c)), rsc = rs + popc32(ts >> (4 - c));  // rank(T, base + c)
-        const int64_t mt_ = vt[c], ms_ = has_s ? p.ms - vs[c] : p.ms;
+        const V mt_ = vt[c], ms_ = has_s ? p.ms - vs[c] : p.ms;
         o->val[c] = mt_ + ms_;
-        NodeSt& n = o->st[c];
+        NodeStT<V>& n = o->st[c];
         n.mt = mt_;
         n.ms = ms_;
         n.bt = WQ_NONE;
@@ -510,10 +524,12 @@ __device__ __forceinline__ void expand4(gbytes b, const TreeRef& S, const DacDes
 
 // (k = 2, sub-windows on the 32-grid: one node per level down to side 32, then at most 4, 16, 64: 96 entries hold every level)
 constexpr int WQ2_CAP = 96;
-struct WaveQ2 {
+template <class V>
+struct WaveQ2T {
     uint32_t it[WQ2_CAP], is[WQ2_CAP], org[WQ2_CAP];
-    int64_t mt[WQ2_CAP], ms[WQ2_CAP];
+    V mt[WQ2_CAP], ms[WQ2_CAP];
 };
+typedef WaveQ2T<int64_t> WaveQ2;
 // What a search item adds to its WinItem (search = the same walk; instead of storing a cell it tests lower <= v <= upper and
 // sets the cell's bit in the sub-window's own 32-word bitmap -- word = row - top, bit = column - left -- at out[item * 32];
 // no two waves share a word, so there is nothing atomic about it and nothing to clear beforehand).
@@ -522,15 +538,17 @@ struct SearchExtra {
 };
 // MW = waves per SIMD the register allocator must leave room for; DENSE64: the batched form's output (int64, unit column stride);
 // SEARCH: mark matches (out = the bitmaps, sx = one SearchExtra per item) instead of storing values
-template <int MW, bool DENSE64, bool SEARCH = false, bool USE_TOP = true>
+template <int MW, bool DENSE64, bool SEARCH = false, class V = int64_t, bool USE_TOP = true>
 __global__ void __launch_bounds__(256, MW)
 k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ items, uint32_t n_items, void* out, int32_t out_dtype,
                const SearchExtra* __restrict__ sx = nullptr) {
-    __shared__ WaveQ2 wq[4];
+    typedef NodeStT<V> NodeSt;
+    typedef KidsT<V> Kids;
+    __shared__ WaveQ2T<V> wq[4];
     __shared__ uint32_t wbits[4][32];  // SEARCH: the sub-window's matches, one word per row (bit = column - wleft)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    WaveQ2& q = wq[wave];
+    WaveQ2T<V>& q = wq[wave];
     uint32_t* const rowbits = wbits[wave];
     for (uint32_t item = blockIdx.x * 4u + (uint32_t)wave; item < n_items; item += gridDim.x * 4u) {
         const WinItem I = items[item];
@@ -600,7 +618,7 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
             const unsigned long long bp = __builtin_amdgcn_ballot_w64(push);
             if (push) {
                 const uint32_t pos = __builtin_amdgcn_mbcnt_lo((uint32_t)bp, 0u);
-                q.it[pos] = ebt; q.is[pos] = ebs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = emt; q.ms[pos] = ems;
+                q.it[pos] = ebt; q.is[pos] = ebs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = (V)emt; q.ms[pos] = (V)ems;
             }
             unsigned long long bf = __builtin_amdgcn_ballot_w64(isfill);
             while (bf) {  // squares of one value: their part of the sub-window, by the whole wave
@@ -630,8 +648,8 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
                 q.it[0] = (has_log && !single_t) ? 1u : WQ_NONE;
                 q.is[0] = single_s ? WQ_NONE : 1u;
                 q.org[0] = 0;
-                q.mt[0] = max_t0;
-                q.ms[0] = max_s0;
+                q.mt[0] = (V)max_t0;
+                q.ms[0] = (V)max_s0;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -677,7 +695,8 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
                         bf &= bf - 1;
                         const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)cr, l), ccl = (uint32_t)__builtin_amdgcn_readlane((int)cc, l);
                         const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kd.val[c], l);
-                        const uint32_t vhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)kd.val[c] >> 32), l);
+                        const uint32_t vhi = sizeof(V) == 4 ? (uint32_t)((int32_t)vlo >> 31)
+                                                            : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)(int64_t)kd.val[c] >> 32), l);
                         fill_wave(rr > wtop ? rr : wtop, rr + cs < wbot ? rr + cs : wbot, ccl > wleft ? ccl : wleft, ccl + cs < wright ? ccl + cs : wright,
                                   (int64_t)(((uint64_t)vhi << 32) | vlo));
                     }
@@ -704,7 +723,7 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
             for (int c = 0; c < 4; c++) {
                 const uint32_t cr = pr + 2u * (uint32_t)(c >> 1), cc = pc + 2u * (uint32_t)(c & 1);
                 if (!inside && !(cr < wbot && cr + 2 > wtop && cc < wright && cc + 2 > wleft)) continue;
-                int64_t v[4] = {kd.val[c], kd.val[c], kd.val[c], kd.val[c]};
+                V v[4] = {kd.val[c], kd.val[c], kd.val[c], kd.val[c]};
                 if (!((kd.fill >> c) & 1u)) {
                     Kids g;
                     expand4(gb, S, SD.mx, L, D.mx, kd.st[c], &g);
@@ -715,8 +734,8 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
                     typedef long long ll2 __attribute__((ext_vector_type(2)));
                     typedef ll2 __attribute__((aligned(8))) ll2u;
                     int64_t* const o0 = (int64_t*)out + (obase + (int64_t)(cr * osr + cc));
-                    *(__attribute__((address_space(1))) ll2u*)o0 = ll2{v[0], v[1]};
-                    *(__attribute__((address_space(1))) ll2u*)(o0 + osr) = ll2{v[2], v[3]};
+                    *(__attribute__((address_space(1))) ll2u*)o0 = ll2{(long long)v[0], (long long)v[1]};
+                    *(__attribute__((address_space(1))) ll2u*)(o0 + osr) = ll2{(long long)v[2], (long long)v[3]};
                     continue;
                 }
 #pragma unroll
@@ -730,7 +749,7 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
         __builtin_amdgcn_wave_barrier();
     }
 }
-// The walk's state at every node of side 32, for every instant of one chunk (dcdf_chunk::d_top): one wave per instant walks
+// The walk's state at every node of side 16, for every instant of one chunk (dcdf_chunk::d_top): one wave per instant walks
 // the top of the tree(s) breadth-first -- 1, 4, 16, ... nodes -- with the same expand4 as the query walks.
 __global__ void __launch_bounds__(64)
 k_top_table(ChunkRef C, TopEnt* __restrict__ table, uint32_t* __restrict__ overflow) {
@@ -969,6 +988,17 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
             d.sidelen < std::max(d.rows, d.cols))
             return DCDF_ERR_FORMAT;
     c->len = len;
+    c->narrow32 = true;
+    for (size_t i = 0; i < c->descs.size(); i++) {
+        const InstDesc& D = c->descs[i];
+        int64_t hi = dacd_get(bytes, D.mx, 0), lo = dacd_get(bytes, D.mn, 0);
+        if (D.is_log) {  // log roots are differences against the snapshot's (log.rs:133,148)
+            hi += dacd_get(bytes, c->descs[D.snap].mx, 0);
+            lo += dacd_get(bytes, c->descs[D.snap].mn, 0);
+        }
+        const int64_t lim = (int64_t)1 << 30;
+        if (hi < -lim || hi >= lim || lo < -lim || lo >= lim) c->narrow32 = false;
+    }
     c->search_quirk.assign(c->descs.size(), 0);
     for (size_t i = 0; i < c->descs.size(); i++) {
         const InstDesc& L = c->descs[i];
@@ -1085,7 +1115,7 @@ static bool wave_kernel_ok(const dcdf_chunk* h) {
 }
 static bool node_kernel_ok(const dcdf_chunk* h) { return h->descs[0].k == 2 && h->descs[0].sidelen >= 4; }
 static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>& items, void* d_out, int32_t dtype, hipEvent_t e0, hipEvent_t e1,
-                               bool node_wise) {
+                               bool node_wise, bool narrow) {
     DevBuf d_items;
     K2R_HIP(d_items.alloc(items.size() * sizeof(WinItem)));
     K2R_HIP(hipMemcpy(d_items.p, items.data(), items.size() * sizeof(WinItem), hipMemcpyHostToDevice));
@@ -1093,7 +1123,9 @@ static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>&
     const uint32_t grid = std::min<uint32_t>((n + 3) / 4, 256u * 16u);
     if (e0) K2R_HIP(hipEventRecord(e0, 0));
     if (node_wise) {
-        if (dtype == DCDF_I64) hipLaunchKernelGGL((k_window_wave2<4, true>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+        if (dtype == DCDF_I64 && narrow) hipLaunchKernelGGL((k_window_wave2<4, true, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+        else if (dtype == DCDF_I64) hipLaunchKernelGGL((k_window_wave2<4, true>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+        else if (narrow) hipLaunchKernelGGL((k_window_wave2<4, false, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
         else hipLaunchKernelGGL((k_window_wave2<4, false>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
     }
     else hipLaunchKernelGGL(k_window_wave, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
@@ -1127,7 +1159,7 @@ extern "C" int dcdf_chunk_fill_window(const dcdf_chunk* h, const dcdf_cube* cube
     if (wave_kernel_ok(h)) {
         std::vector<WinItem> items;
         window_items(0, c, 0, items);
-        const int rc = launch_window_items(d_ref, items, d_o.p, out_dtype, nullptr, nullptr, node_kernel_ok(h));
+        const int rc = launch_window_items(d_ref, items, d_o.p, out_dtype, nullptr, nullptr, node_kernel_ok(h), h->narrow32);
         if (rc != DCDF_OK) return rc;
     } else {
         hipLaunchKernelGGL(k_fill_window, dim3(1), dim3(256), 0, 0, d_ref.as<ChunkRef>(), d_q.as<WinQuery>(), 1u, d_o.p,
@@ -1255,8 +1287,14 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         const uint32_t ni = (uint32_t)items.size();
         K2R_HIP(hipEventRecord(e0, 0));
         if (nw) {
-            hipLaunchKernelGGL((k_window_wave2<4, false, true>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
-                               d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
+            bool all_narrow = true;
+            for (const dcdf_chunk* u : uniq) all_narrow = all_narrow && u->narrow32;
+            if (all_narrow)
+                hipLaunchKernelGGL((k_window_wave2<4, false, true, int32_t>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
+                                   d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
+            else
+                hipLaunchKernelGGL((k_window_wave2<4, false, true>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
+                                   d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
             hipLaunchKernelGGL(k_search_count, dim3((ni + 63) / 64), dim3(64), 0, 0, d_wbits.as<uint32_t>(), d_items.as<SearchItem>(),
                                d_qs.as<WinQuery>(), ni, d_counts.as<uint32_t>());
         }
@@ -1360,9 +1398,11 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
     EventPair ev;
     K2R_HIP(ev.create());
     bool all_wave = true, all_node = true;
+    bool all_narrow = true;
     for (const dcdf_chunk* u : uniq) {
         all_wave = all_wave && wave_kernel_ok(u);
         all_node = all_node && node_kernel_ok(u);
+        all_narrow = all_narrow && u->narrow32;
     }
     if (all_wave) {
         std::vector<WinItem> items;
@@ -1370,7 +1410,7 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
             const dcdf_cube c{qs[q].start, qs[q].end, qs[q].top, qs[q].bottom, qs[q].left, qs[q].right};
             window_items(qs[q].chunk, c, qs[q].out_off, items);
         }
-        rc = launch_window_items(d_refs, items, d_o.p, (int32_t)DCDF_I64, ev.e0, ev.e1, all_node);
+        rc = launch_window_items(d_refs, items, d_o.p, (int32_t)DCDF_I64, ev.e0, ev.e1, all_node, all_narrow);
         if (rc != DCDF_OK) return rc;
     } else {
         const uint32_t grid = (uint32_t)std::min<size_t>(nq, 1u << 20);
