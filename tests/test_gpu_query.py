@@ -190,6 +190,42 @@ def test_synthetic_256_roundtrip_and_batches(dc):
         assert got == brute(a, s, e, t, bo, l, r, int(lower[q]), int(upper[q]))
 
 
+@pytest.mark.parametrize("kind", ["beyond_2_30", "beyond_int32", "int64_extremes"])
+def test_wide_value_chunks_take_the_64_bit_walk(dc, kind):
+    """The query walks run on 32-bit values only for chunks whose values lie in [-2^30, 2^30) and start from the per-instant
+    top table only when its entries fit int32: chunks outside either range take the 64-bit instantiation / the walk from the
+    root, with the same results (windows == the array, search == brute force, both against the oracle's decode too)."""
+    rng = np.random.default_rng({"beyond_2_30": 1, "beyond_int32": 2, "int64_extremes": 3}[kind])
+    side = 64
+    a = rng.integers(-500, 500, size=(6, side, side)).astype(np.int64)
+    a[2] = a[1]
+    a[3] = a[1] + 9
+    a[4, :40, :24] = a[1, :40, :24]
+    if kind == "beyond_2_30":
+        a[:, 5, 7] += 2 ** 30 + 12345          # narrow32 false, the table's entries still fit int32
+    elif kind == "beyond_int32":
+        a[:, 5, 7] += 2 ** 33
+        a[3, 40, 41] = -(2 ** 35)              # no top table for this chunk
+    else:
+        a[0, 0, 0] = 2 ** 62
+        a[5, 63, 63] = -(2 ** 62)
+        a[4, 10:20, 10:20] += 2 ** 50
+    data = O.chunk_build(a)
+    c = dc.Chunk(data)
+    assert c.write_to() == data
+    np.testing.assert_array_equal(c.fill_window(dc.Cube(0, 6, 0, side, 0, side)), a)
+    for _ in range(40):
+        s = int(rng.integers(6)); e = min(6, s + int(rng.integers(1, 4)))
+        t = int(rng.integers(side)); bo = min(side, t + int(rng.integers(1, 50)))
+        l = int(rng.integers(side)); r = min(side, l + int(rng.integers(1, 50)))
+        np.testing.assert_array_equal(c.fill_window(dc.Cube(s, e, t, bo, l, r)), a[s:e, t:bo, l:r])
+        lo = int(rng.integers(-600, 600)); hi = lo + int(rng.integers(0, 400))
+        if rng.random() < 0.3:
+            hi = 2 ** 62
+        got = set(map(tuple, c.iter_search(dc.Cube(s, e, t, bo, l, r), lo, hi).tolist()))
+        assert got == brute(a, s, e, t, bo, l, r, lo, hi)
+
+
 def test_suggest_fraction_golden_and_random(dc):  # fixed.rs:96-159, tests fixed.rs:311-401
     import json, os
     G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
