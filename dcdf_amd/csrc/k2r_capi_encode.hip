@@ -185,12 +185,10 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
     // diagnostic knob (A/B runs): cap the LDS words the log stash may use; 1 = always take the re-reading passes
     uint32_t stash_words = 0;
     if (const char* sw = std::getenv("K2R_STASH_WORDS")) stash_words = (uint32_t)std::atoi(sw);
-    const uint32_t tile_flags = std::getenv("K2R_NO_FAST") ? 1u : 0u;  // A/B runs: general path only
     for (size_t i = 0; i < n; i++) {
         const dcdf_tile_desc& t = tiles[i];
         TileArgs a{};
         a.stash_words = stash_words;
-        a.flags = tile_flags;
         a.base = t.base;
         a.st = t.stride_t; a.sr = t.stride_r; a.sc = t.stride_c;
         a.instants = t.instants; a.rows = t.rows; a.cols = t.cols;

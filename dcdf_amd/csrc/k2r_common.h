@@ -51,7 +51,7 @@ struct TileArgs {  // one Chunk::build input (device-visible copy of dcdf_tile_d
     uint64_t out_cap;  // bytes
     int64_t* minmax;   // [instants][2] or null
     uint32_t stash_words;  // 0 = default; else caps the LDS words the log stash may use (k2r_encode.h; tests, A/B runs)
-    uint32_t flags;        // bit 0: do not use the fast log path (k2r_fastlog.h): tests, A/B runs
+    uint32_t _reserved;
 };
 
 constexpr int NPROF = 20;
@@ -62,7 +62,7 @@ struct TileResult {
     uint32_t stash_logs;  // diagnostic: logs emitted from the LDS stash (no re-read of the input)
     uint64_t len;
     uint32_t dbg[6];  // guard record when status == ST_INTERNAL: count, code, instant, tid, value, limit
-    uint32_t fast_logs;   // diagnostic: logs emitted by the level-order streaming path (k2r_fastlog.h)
+    uint32_t _pad1;
     uint32_t _pad2;
     uint64_t prof[NPROF];  // shader-clock cycles per phase (only filled by -DK2R_PROFILE diagnostic builds)
 };

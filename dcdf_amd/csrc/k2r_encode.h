@@ -954,7 +954,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     if (!EX::kSim) ex.par([&](int tid, EncRegs&) { if (tid == 0) sh.prof_last = clock64(); });
 #endif
 
-    uint32_t n_fast = 0;
     for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
         const bool have_s = inst > 0;
         // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
@@ -1511,9 +1510,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             n_snap++;
             const int32_t rmin = ex.uni(sh.tmin[C::top_off(H)]), rmax = ex.uni(sh.tmax[C::top_off(H)]);
             s_cmp = (int64_t)rmax - (int64_t)rmin <= 65535 && inst + 1 < ta.instants;
-            // the 16-bit window of the compact copy is centred on the snapshot's range: the fast log path (k2r_fastlog.h)
-            // needs the LATER instants of the block inside it too, and those drift either way
-            s_base = s_cmp ? rmin - (65535 - (rmax - rmin)) / 2 : rmin;
+            s_base = rmin;
         } else {
             n_log++;
         }
@@ -1947,7 +1944,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             res->snapshots = n_snap;
             res->logs = n_log;
             res->stash_logs = n_stash;
-            res->fast_logs = n_fast;
             res->len = (status == ST_OK && !faulted) ? off : 0;
             for (int i = 0; i < 6; i++) res->dbg[i] = sh.fault[i];
             for (int i = 0; i < NPROF; i++) res->prof[i] = sh.prof[i];

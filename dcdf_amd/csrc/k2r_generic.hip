@@ -407,7 +407,6 @@ __device__ void gen_encode_tile(GenShared& sh, const TileArgs& ta, TileResult* r
         res->snapshots = n_snap;
         res->logs = n_log;
         res->stash_logs = 0;
-        res->fast_logs = 0;
         res->len = (status == ST_OK || status == ST_OUT_CAPACITY) ? off : 0;  // on OUT_CAPACITY: the bytes a retry needs
         for (int i = 0; i < 6; i++) res->dbg[i] = 0;
     }

@@ -33,9 +33,8 @@ static void run_l(const TileArgs& ta, TileResult* res, bool padded, int vec) {
     else run<LOG2S, false, 0>(ta, res);
 }
 
-static uint32_t g_last_stash_logs = 0, g_last_fast_logs = 0;
+static uint32_t g_last_stash_logs = 0;
 extern "C" uint32_t sim_last_stash_logs() { return g_last_stash_logs; }
-extern "C" uint32_t sim_last_fast_logs() { return g_last_fast_logs; }
 
 extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, int64_t sc, uint32_t instants,
                           uint32_t rows, uint32_t cols, int fbits, int round, uint8_t* out, uint64_t cap,
@@ -46,7 +45,6 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
     ta.instants = instants; ta.rows = rows; ta.cols = cols;
     ta.dtype = dtype; ta.fbits = (dtype == ENC_F32 || dtype == ENC_F64) ? (uint32_t)fbits : 0; ta.round = (uint32_t)round;
     ta.out = out; ta.out_cap = cap; ta.minmax = minmax;
-    if (std::getenv("K2R_SIM_NO_FAST")) ta.flags |= 1u;  // general path only
     if (const char* sw = std::getenv("K2R_SIM_STASH_WORDS")) ta.stash_words = (uint32_t)std::atoi(sw);  // force the fallback passes
     uint32_t m = rows > cols ? rows : cols;
     int lg = 0;
@@ -69,7 +67,6 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
         case 8: run_l<8>(ta, &res, padded, vec); break;
     }
     g_last_stash_logs = res.stash_logs;
-    g_last_fast_logs = res.fast_logs;
     *status = res.status; *snapshots = res.snapshots; *logs = res.logs; *len = res.len;
     return 0;
 }
