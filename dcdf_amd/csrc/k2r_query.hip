@@ -25,7 +25,7 @@ struct dcdf_chunk {
     // k = 2, sidelen 32..256: for every instant the walk's state at each node of side 16 (k_top_table, built at open): the wave
     // walks of fill_window / search start there instead of at the root (an item never leaves one square of the 32-grid: it
     // begins with that square's four entries)
-    DevBuf d_top;
+    DevBuf d_top, d_top_mm;
     uint32_t top_g = 0;  // squares per side (sidelen / 16), 0 = no table
     // every stored value of every instant lies in [-2^30, 2^30) (from the root extremes): the query walks then run on 32-bit
     // values (NodeStT<int32_t>).  (A crafted chunk whose inner Dac values contradict its roots decodes to different garbage than
@@ -55,11 +55,15 @@ struct TopEnt {  // the walk's state at one node (log.rs:360-361): both first-ch
     uint32_t bt, bs;
     int32_t mt, ms;  // (a chunk with a value beyond int32 gets no table: k_top_table reports it)
 };
+struct TopMM {  // smallest and largest value inside the same square (the reference's own pruning bounds: log.rs:573-574)
+    int32_t vmin, vmax;
+};
 struct ChunkRef {  // device-visible handle of an opened chunk
     const uint8_t* bytes;
     const InstDesc* descs;
     uint32_t instants, rows, cols, fbits;
     const TopEnt* top;  // [instant][top_g * top_g] or null
+    const TopMM* top_mm;  // the same squares' value ranges (search prunes with them)
     uint32_t top_g, _pad;
 };
 
@@ -614,7 +618,27 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
                 const u32x4 x = *(__attribute__((address_space(1))) const u32x4*)e;
                 ebt = x.x; ebs = x.y; emt = (int32_t)x.z; ems = (int32_t)x.w;
             }
-            const bool isfill = mine && ebt == WQ_NONE && ebs == WQ_NONE, push = mine && !isfill;
+            // search: the square's value range decides without a descent when it lies outside or inside [lower, upper]
+            // (the reference prunes the same way at every node, log.rs:575-586; here once, at side 16)
+            bool skip = false, force = false;
+            if (SEARCH && mine) {
+                typedef __attribute__((address_space(1))) const TopMM* gmm;
+                const gmm m = (gmm)C.top_mm + ((size_t)I.inst * C.top_g + (cr >> 4)) * C.top_g + (cc >> 4);
+                const int64_t vmin = m->vmin, vmax = m->vmax;
+                skip = vmax < s_lo || vmin > s_hi;
+                force = !skip && s_lo <= vmin && vmax <= s_hi;
+            }
+            const bool isfill = mine && !skip && !force && ebt == WQ_NONE && ebs == WQ_NONE;
+            const bool push = mine && !skip && !force && !isfill;
+            if (SEARCH) {
+                unsigned long long bo = __builtin_amdgcn_ballot_w64(force);
+                while (bo) {  // every cell of the square matches: its part of the sub-window at once
+                    const int l = __builtin_ctzll(bo);
+                    bo &= bo - 1;
+                    const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)cr, l), ccl = (uint32_t)__builtin_amdgcn_readlane((int)cc, l);
+                    fill_wave(rr > wtop ? rr : wtop, rr + 16 < wbot ? rr + 16 : wbot, ccl > wleft ? ccl : wleft, ccl + 16 < wright ? ccl + 16 : wright, s_lo);
+                }
+            }
             const unsigned long long bp = __builtin_amdgcn_ballot_w64(push);
             if (push) {
                 const uint32_t pos = __builtin_amdgcn_mbcnt_lo((uint32_t)bp, 0u);
@@ -752,8 +776,9 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
 // The walk's state at every node of side 16, for every instant of one chunk (dcdf_chunk::d_top): one wave per instant walks
 // the top of the tree(s) breadth-first -- 1, 4, 16, ... nodes -- with the same expand4 as the query walks.
 __global__ void __launch_bounds__(64)
-k_top_table(ChunkRef C, TopEnt* __restrict__ table, uint32_t* __restrict__ overflow) {
+k_top_table(ChunkRef C, TopEnt* __restrict__ table, TopMM* __restrict__ table_mm, uint32_t* __restrict__ overflow) {
     __shared__ WaveQ2 q;
+    __shared__ int64_t qmt[WQ2_CAP], qms[WQ2_CAP];  // the frontier nodes' min_t, min_s (log.rs:360-361)
     const int lane = threadIdx.x;
     const uint32_t inst = blockIdx.x, G = C.top_g;
     const uint8_t* const b = C.bytes;
@@ -765,18 +790,26 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table, uint32_t* __restrict__ overf
     const InstDesc& SD = has_log ? C.descs[gD->snap] : D;
     const TreeRef S = tree_ref(gS), L = tree_ref(gD);
     TopEnt* const out = table + (size_t)inst * G * G;
-    auto put_square = [&](uint32_t r, uint32_t c, uint32_t sd, uint32_t bt, uint32_t bs, int64_t mt, int64_t ms) {  // every 16-square of the node
-        if (mt != (int32_t)mt || ms != (int32_t)ms) *overflow = 1;
+    TopMM* const omm = table_mm + (size_t)inst * G * G;
+    // every 16-square of the node at (r, c), side sd: the walk's state there and the range of the values inside
+    auto put_square = [&](uint32_t r, uint32_t c, uint32_t sd, uint32_t bt, uint32_t bs, int64_t mt, int64_t ms, int64_t vmin, int64_t vmax) {
+        if (mt != (int32_t)mt || ms != (int32_t)ms || vmin != (int32_t)vmin || vmax != (int32_t)vmax) *overflow = 1;
         const TopEnt e{bt, bs, (int32_t)mt, (int32_t)ms};
+        const TopMM m{(int32_t)vmin, (int32_t)vmax};
         const uint32_t n = sd >> 4;
-        for (uint32_t i = 0; i < n * n; i++) out[((r >> 4) + i / n) * G + (c >> 4) + i % n] = e;
+        for (uint32_t i = 0; i < n * n; i++) {
+            const uint32_t at = ((r >> 4) + i / n) * G + (c >> 4) + i % n;
+            out[at] = e;
+            omm[at] = m;
+        }
     };
     const bool single_s = !gbm_get(gb, S.T, 0);
     const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
     const int64_t max_s0 = dacd_get(b, SD.mx, 0), max_t0 = has_log ? dacd_get(b, D.mx, 0) : 0;
+    const int64_t min_s0 = dacd_get(b, SD.mn, 0), min_t0 = has_log ? dacd_get(b, D.mn, 0) : 0;
     const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
     if (all_one) {
-        if (lane == 0) put_square(0, 0, G * 16, WQ_NONE, WQ_NONE, max_t0, max_s0);
+        if (lane == 0) put_square(0, 0, G * 16, WQ_NONE, WQ_NONE, max_t0, max_s0, max_t0 + max_s0, max_t0 + max_s0);
         return;
     }
     if (lane == 0) {
@@ -785,6 +818,8 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table, uint32_t* __restrict__ overf
         q.org[0] = 0;
         q.mt[0] = max_t0;
         q.ms[0] = max_s0;
+        qmt[0] = min_t0;
+        qms[0] = min_s0;
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t lo = 0, hi = 1;
@@ -794,8 +829,12 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table, uint32_t* __restrict__ overf
         Kids kd;
         kd.fill = 0;
         uint32_t po = 0;
+        NodeSt p{WQ_NONE, WQ_NONE, 0, 0};
+        int64_t pmin_t = 0, pmin_s = 0;
         if (live) {
-            const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+            p = NodeSt{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+            pmin_t = qmt[n];
+            pmin_s = qms[n];
             po = q.org[n];
             expand4(gb, S, SD.mx, L, D.mx, p, &kd);
         }
@@ -806,12 +845,28 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table, uint32_t* __restrict__ overf
         for (int c = 0; c < 4; c++) {
             if (!live) continue;
             const uint32_t cr = (po >> 16) + (uint32_t)(c >> 1) * cs, cc = (po & 0xffffu) + (uint32_t)(c & 1) * cs;
+            // the child's minima, as the reference's search carries them (log.rs:640-676; snapshot.rs:391 without a log)
+            const bool has_t = p.bt != WQ_NONE, has_s = p.bs != WQ_NONE;
+            const uint32_t it_ = has_t ? p.bt + (uint32_t)c : 0u, is_ = has_s ? p.bs + (uint32_t)c : 0u;
+            const bool leaf_t = has_t ? (it_ >= D.T.len || !bmd_get(b, D.T, it_)) : true;
+            const bool leaf_s = has_s ? (is_ >= SD.T.len || !bmd_get(b, SD.T, is_)) : true;
+            const int64_t mt_ = kd.st[c].mt, ms_ = kd.st[c].ms;
+            int64_t min_t_ = has_t ? (leaf_t ? pmin_t : dacd_get(b, D.mn, bmd_rank(b, D.T, it_))) : pmin_t;
+            int64_t min_s_ = has_s ? (leaf_s ? pmin_s : pmin_s + dacd_get(b, SD.mn, bmd_rank(b, SD.T, is_))) : pmin_s;
+            if (leaf_s) min_s_ = ms_;
+            if (leaf_t) {
+                min_t_ = mt_;
+                if (has_t && it_ < D.T.len && !bmd_get(b, D.E, bmd_rank0(b, D.T, it_ + 1) - 1)) min_t_ = ms_ + mt_ - min_s_;
+            }
+            const int64_t vmax = ms_ + mt_, vmin = min_s_ + min_t_;
             if ((kd.fill >> c) & 1u) {
-                put_square(cr, cc, cs, WQ_NONE, WQ_NONE, kd.st[c].mt, kd.st[c].ms);
+                put_square(cr, cc, cs, WQ_NONE, WQ_NONE, mt_, ms_, vmax, vmax);
             } else if (cs == 16) {
-                put_square(cr, cc, 16, kd.st[c].bt, kd.st[c].bs, kd.st[c].mt, kd.st[c].ms);
+                put_square(cr, cc, 16, kd.st[c].bt, kd.st[c].bs, mt_, ms_, vmin, vmax);
             } else {
-                q.it[pos] = kd.st[c].bt; q.is[pos] = kd.st[c].bs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = kd.st[c].mt; q.ms[pos] = kd.st[c].ms;
+                q.it[pos] = kd.st[c].bt; q.is[pos] = kd.st[c].bs; q.org[pos] = (cr << 16) | cc; q.mt[pos] = mt_; q.ms[pos] = ms_;
+                qmt[pos] = min_t_;
+                qms[pos] = min_s_;
                 pos++;
             }
         }
@@ -1011,11 +1066,12 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
     if (c->descs[0].k == 2 && c->descs[0].sidelen >= 32 && c->descs[0].sidelen <= 256 && !std::getenv("K2R_NO_TOP_TABLE")) {
         const uint32_t g = c->descs[0].sidelen / 16;
         const size_t tbytes = (size_t)c->instants * g * g * sizeof(TopEnt);
+        K2R_HIP(c->d_top_mm.alloc((size_t)c->instants * g * g * sizeof(TopMM)));
         K2R_HIP(c->d_top.alloc(tbytes + 4));  // (+ the "a value does not fit int32" word)
         uint32_t* const d_ovf = (uint32_t*)(c->d_top.as<uint8_t>() + tbytes);
         K2R_HIP(hipMemset(d_ovf, 0, 4));
-        ChunkRef ref{c->d_bytes.as<uint8_t>(), c->d_descs.as<InstDesc>(), c->instants, c->rows, c->cols, c->fbits, nullptr, g, 0};
-        hipLaunchKernelGGL(k_top_table, dim3(c->instants), dim3(64), 0, 0, ref, c->d_top.as<TopEnt>(), d_ovf);
+        ChunkRef ref{c->d_bytes.as<uint8_t>(), c->d_descs.as<InstDesc>(), c->instants, c->rows, c->cols, c->fbits, nullptr, nullptr, g, 0};
+        hipLaunchKernelGGL(k_top_table, dim3(c->instants), dim3(64), 0, 0, ref, c->d_top.as<TopEnt>(), c->d_top_mm.as<TopMM>(), d_ovf);
         K2R_HIP(hipGetLastError());
         uint32_t ovf = 0;
         K2R_HIP(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
@@ -1041,7 +1097,7 @@ extern "C" int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* 
 
 static ChunkRef make_ref(const dcdf_chunk* h) {
     return ChunkRef{h->d_bytes.as<uint8_t>(), h->d_descs.as<InstDesc>(), h->instants, h->rows, h->cols, h->fbits,
-                    h->top_g ? h->d_top.as<TopEnt>() : nullptr, h->top_g, 0};
+                    h->top_g ? h->d_top.as<TopEnt>() : nullptr, h->top_g ? h->d_top_mm.as<TopMM>() : nullptr, h->top_g, 0};
 }
 // geom::Cube::new reorders reversed bounds (geom.rs:83-103)
 static dcdf_cube norm_cube(const dcdf_cube& c) {

@@ -155,8 +155,9 @@ typedef struct dcdf_cube {
 } dcdf_cube;
 
 /* Replaces `Chunk::read_from` (chunk.rs:247-266) + upload.  `bytes` is host memory.  The stream is validated structurally
- * (DCDF_ERR_FORMAT otherwise) and copied to the device; for k = 2 chunks of sidelen 32..256 a 16-byte entry per 16 x 16
- * square and instant is built next to it on the device (where the query walks of that square start). */
+ * (DCDF_ERR_FORMAT otherwise) and copied to the device; for k = 2 chunks of sidelen 32..256 a 24-byte entry per 16 x 16
+ * square and instant is built next to it on the device (where the query walks of that square start, and the square's value
+ * range, which search prunes with). */
 int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h);
 void dcdf_chunk_close(dcdf_chunk* h);
 /* Chunk::shape (chunk.rs:119-123), encoding / fractional_bits (chunk.rs:33-38), block count. */
