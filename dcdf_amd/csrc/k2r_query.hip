@@ -156,8 +156,8 @@ k_fill_window(const ChunkRef* __restrict__ chunks, const WinQuery* __restrict__ 
 struct SearchItem {
     uint32_t query, instant;  // instant is absolute within the chunk
     uint64_t bits_off;        // u32 words: the item's window bitmap, row-major over the query window (per-thread descent)
-    uint32_t w0, ncb;         // wave walk: first of the item's sub-window bitmaps (32 words each, [row block][column block]) and
-                              // column blocks per row block; w0 == SI_FLAT: the flat bitmap above is the one in use
+    uint32_t w0, ncb;         // wave walk: first of the item's pieces (<= 64 x 64 cells from the window's origin, row-major; a bitmap
+                              // of 64 rows x 2 words each) and pieces per row; w0 == SI_FLAT: the flat bitmap above is the one in use
 };
 constexpr uint32_t SI_FLAT = 0xffffffffu;
 // ---- wave-cooperative window decode ---------------------------------------------------------------------------------------
@@ -526,8 +526,9 @@ __device__ __forceinline__ void expand4(gbytes b, const TreeRef& S, const DacDes
     }
 }
 
-// (k = 2, sub-windows on the 32-grid: one node per level down to side 32, then at most 4, 16, 64: 96 entries hold every level)
-constexpr int WQ2_CAP = 96;
+// (k = 2, items of at most 64 x 64 cells: they meet at most 5 x 5 nodes of side 16, 9 x 9 of side 8, 17 x 17 of side 4 -- 395
+//  frontier entries below the top table; walking from the root adds at most 1 + 4 + 4 + 9 above them)
+constexpr int WQ2_CAP = 448;
 template <class V>
 struct WaveQ2T {
     uint32_t it[WQ2_CAP], is[WQ2_CAP], org[WQ2_CAP];
@@ -540,7 +541,8 @@ typedef WaveQ2T<int64_t> WaveQ2;
 struct SearchExtra {
     int64_t lower, upper;
 };
-// MW = waves per SIMD the register allocator must leave room for; DENSE64: the batched form's output (int64, unit column stride);
+// MW = waves per SIMD the register allocator must leave room for (4 for the 32-bit walk; the 64-bit one's frontier leaves LDS
+// for 3 workgroups per CU, so it is built for 3); DENSE64: the batched form's output (int64, unit column stride);
 // SEARCH: mark matches (out = the bitmaps, sx = one SearchExtra per item) instead of storing values
 template <int MW, bool DENSE64, bool SEARCH = false, class V = int64_t, bool USE_TOP = true>
 __global__ void __launch_bounds__(256, MW)
@@ -549,7 +551,7 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
     typedef NodeStT<V> NodeSt;
     typedef KidsT<V> Kids;
     __shared__ WaveQ2T<V> wq[4];
-    __shared__ uint32_t wbits[4][32];  // SEARCH: the sub-window's matches, one word per row (bit = column - wleft)
+    __shared__ uint32_t wbits[4][128];  // SEARCH: the item's matches, two words per row (bit = column - wleft)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveQ2T<V>& q = wq[wave];
@@ -572,12 +574,14 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
         if (SEARCH) {
             s_lo = sx[item].lower;
             s_hi = sx[item].upper;
-            if (lane < 32) rowbits[lane] = 0;
+            rowbits[2 * lane] = 0;
+            rowbits[2 * lane + 1] = 0;
             __builtin_amdgcn_wave_barrier();
         }
         auto put = [&](uint32_t r, uint32_t c, int64_t v) {
             if (SEARCH) {
-                if (s_lo <= v && v <= s_hi) atomicOr(&rowbits[r - wtop], 1u << (c - wleft));
+                const uint32_t j = c - wleft;
+                if (s_lo <= v && v <= s_hi) atomicOr(&rowbits[2 * (r - wtop) + (j >> 5)], 1u << (j & 31u));
                 return;
             }
             const int64_t off = obase + (int64_t)(r * osr + c);
@@ -587,29 +591,39 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
         auto flush_bits = [&]() {
             if (!SEARCH) return;
             __builtin_amdgcn_wave_barrier();
-            if (lane < 32) ((uint32_t*)out)[(uint64_t)item * 32u + (uint32_t)lane] = rowbits[lane];  // (rows beyond the sub-window: 0)
+            ((uint32_t*)out)[(uint64_t)item * 128u + 2u * (uint32_t)lane] = rowbits[2 * lane];  // (rows beyond the item: 0)
+            ((uint32_t*)out)[(uint64_t)item * 128u + 2u * (uint32_t)lane + 1u] = rowbits[2 * lane + 1];
             __builtin_amdgcn_wave_barrier();
         };
         auto fill_wave = [&](uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int64_t v) {
             if (SEARCH) {  // (v is wave-uniform) a rectangle of one value: whole row segments at once
                 if (s_lo <= v && v <= s_hi && (uint32_t)lane < r1 - r0 && c1 > c0) {
                     const uint32_t w1 = c1 - c0;
-                    atomicOr(&rowbits[r0 - wtop + (uint32_t)lane], (w1 >= 32u ? 0xffffffffu : ((1u << w1) - 1u)) << (c0 - wleft));
+                    const uint64_t m = (w1 >= 64u ? ~0ull : ((1ull << w1) - 1ull)) << (c0 - wleft);
+                    uint32_t* const rw = &rowbits[2 * (r0 - wtop + (uint32_t)lane)];
+                    if ((uint32_t)m) atomicOr(rw, (uint32_t)m);
+                    if ((uint32_t)(m >> 32)) atomicOr(rw + 1, (uint32_t)(m >> 32));
                 }
                 return;
             }
-            const uint32_t w = c1 - c0, area = (r1 - r0) * w;      // w <= 32, area <= 1024
-            const uint32_t inv = (65536u + w - 1) / w;             // i / w == (i * inv) >> 16 for i < 2048
-            for (uint32_t i = (uint32_t)lane; i < area; i += 64) {
-                const uint32_t rr = (i * inv) >> 16;
-                put(r0 + rr, c0 + i - rr * w, v);
+            const uint32_t w = c1 - c0, area = (r1 - r0) * w;
+            if (w <= 32 && area <= 1024) {                             // (every fill below the top table)
+                const uint32_t inv = (65536u + w - 1) / w;             // i / w == (i * inv) >> 16 for i < 2048
+                for (uint32_t i = (uint32_t)lane; i < area; i += 64) {
+                    const uint32_t rr = (i * inv) >> 16;
+                    put(r0 + rr, c0 + i - rr * w, v);
+                }
+            } else {
+                for (uint32_t i = (uint32_t)lane; i < area; i += 64) put(r0 + i / w, c0 + i % w, v);
             }
         };
         uint32_t lo = 0, hi = 1, side = sidelen0;
-        if (USE_TOP && C.top) {  // start at the (up to four) nodes of side 16 that hold the sub-window (k_top_table)
+        if (USE_TOP && C.top) {  // start at the (up to 5 x 5) nodes of side 16 that meet the item (k_top_table)
             typedef __attribute__((address_space(1))) const TopEnt* gtop;
-            const uint32_t cr = (wtop & ~31u) + (uint32_t)((lane >> 1) & 1) * 16u, cc = (wleft & ~31u) + (uint32_t)(lane & 1) * 16u;
-            const bool mine = lane < 4 && cr < wbot && cr + 16 > wtop && cc < wright && cc + 16 > wleft;
+            const uint32_t r16 = wtop >> 4, c16 = wleft >> 4, nr16 = ((wbot - 1u) >> 4) - r16 + 1u, nc16 = ((wright - 1u) >> 4) - c16 + 1u;  // <= 5 each
+            const uint32_t qi = (uint32_t)lane / nc16, qj = (uint32_t)lane - qi * nc16;
+            const uint32_t cr = (r16 + qi) << 4, cc = (c16 + qj) << 4;
+            const bool mine = (uint32_t)lane < nr16 * nc16;
             uint32_t ebt = WQ_NONE, ebs = WQ_NONE;
             int64_t emt = 0, ems = 0;
             if (mine) {
@@ -885,10 +899,10 @@ k_search_count(const uint32_t* __restrict__ wbits, const SearchItem* __restrict_
     const SearchItem I = items[it];
     if (I.w0 == SI_FLAT) return;  // (counted by k_search_mark)
     const WinQuery Q = qs[I.query];
-    const uint32_t nrb = ((Q.bottom + 31u) >> 5) - (Q.top >> 5);
-    const uint4* w = (const uint4*)(wbits + (uint64_t)I.w0 * 32u);
+    const uint32_t nrb = (Q.bottom - Q.top + 63u) >> 6;
+    const uint4* w = (const uint4*)(wbits + (uint64_t)I.w0 * 128u);
     uint32_t cnt = 0;
-    for (uint32_t i = 0; i < nrb * I.ncb * 8u; i++) {
+    for (uint32_t i = 0; i < nrb * I.ncb * 32u; i++) {
         const uint4 x = w[i];
         cnt += popc32(x.x) + popc32(x.y) + popc32(x.z) + popc32(x.w);
     }
@@ -938,19 +952,17 @@ k_search_emit(const WinQuery* __restrict__ qs, const SearchItem* __restrict__ it
     const uint32_t wc = Q.right - Q.left, nbits = (Q.bottom - Q.top) * wc;
     const uint32_t* bw = bits + I.bits_off;
     uint32_t* o = out + 3 * offs[it];
-    if (I.w0 != SI_FLAT) {  // sub-window bitmaps of the wave walk: rows in order, column blocks left to right
-        const uint32_t rb0 = Q.top >> 5, cb0 = Q.left >> 5;
+    if (I.w0 != SI_FLAT) {  // the pieces' bitmaps (64 rows x 2 words) of the wave walk: rows in order, pieces left to right
         for (uint32_t r = Q.top; r < Q.bottom; r++) {
-            const uint32_t rb = (r >> 5) - rb0, sub_top = rb == 0 ? Q.top : (r & ~31u);
-            for (uint32_t cb = 0; cb < I.ncb; cb++) {
-                uint32_t x = wbits[((uint64_t)I.w0 + rb * I.ncb + cb) * 32u + (r - sub_top)];
-                const uint32_t sub_left = cb == 0 ? Q.left : ((cb0 + cb) << 5);
+            const uint32_t rb = (r - Q.top) >> 6, rr = (r - Q.top) & 63u;
+            for (uint32_t cw = 0; cw < 2u * I.ncb; cw++) {
+                uint32_t x = wbits[((uint64_t)I.w0 + rb * I.ncb + (cw >> 1)) * 128u + 2u * rr + (cw & 1u)];
                 while (x) {
                     const uint32_t j = (uint32_t)__builtin_ctz(x);
                     x &= x - 1;
                     o[0] = I.instant;
                     o[1] = r;
-                    o[2] = sub_left + j;
+                    o[2] = Q.left + 32u * cw + j;
                     o += 3;
                 }
             }
@@ -1147,18 +1159,21 @@ extern "C" int dcdf_chunk_fill_cell(const dcdf_chunk* h, uint32_t start, uint32_
 
 // (query, instant, sub-window) items of the wave kernel: sub-windows are the 32 x 32 squares of the chunk's grid that the
 // window meets, so that a frontier level never exceeds what a wave's LDS queue holds (k2r::WQ_CAP)
-static void window_items(uint32_t chunk, const dcdf_cube& c, uint64_t out_base, std::vector<WinItem>& items) {
+// node_wise: pieces of at most 64 x 64 cells from the window's origin (k_window_wave2); else the squares of the chunk's 32-grid
+// the window meets (k_window_wave)
+static void window_items(uint32_t chunk, const dcdf_cube& c, uint64_t out_base, std::vector<WinItem>& items, bool node_wise) {
     const uint64_t wr = c.bottom - c.top, wc = c.right - c.left;
+    const uint32_t step = node_wise ? 64u : 32u;
     for (uint32_t t = c.start; t < c.end; t++)
-        for (uint32_t r = c.top & ~31u; r < c.bottom; r += 32)
-            for (uint32_t cc = c.left & ~31u; cc < c.right; cc += 32) {
+        for (uint32_t r = node_wise ? c.top : (c.top & ~31u); r < c.bottom; r += step)
+            for (uint32_t cc = node_wise ? c.left : (c.left & ~31u); cc < c.right; cc += step) {
                 WinItem it{};
                 it.chunk = chunk;
                 it.inst = t;
                 it.top = (uint16_t)std::max(r, c.top);
-                it.bottom = (uint16_t)std::min(r + 32, c.bottom);
+                it.bottom = (uint16_t)std::min(r + step, c.bottom);
                 it.left = (uint16_t)std::max(cc, c.left);
-                it.right = (uint16_t)std::min(cc + 32, c.right);
+                it.right = (uint16_t)std::min(cc + step, c.right);
                 it.out_sr = (uint32_t)wc;
                 it.out_off = out_base + ((uint64_t)(t - c.start) * wr + (it.top - c.top)) * wc + (it.left - c.left);
                 items.push_back(it);
@@ -1180,9 +1195,9 @@ static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>&
     if (e0) K2R_HIP(hipEventRecord(e0, 0));
     if (node_wise) {
         if (dtype == DCDF_I64 && narrow) hipLaunchKernelGGL((k_window_wave2<4, true, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
-        else if (dtype == DCDF_I64) hipLaunchKernelGGL((k_window_wave2<4, true>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+        else if (dtype == DCDF_I64) hipLaunchKernelGGL((k_window_wave2<3, true>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
         else if (narrow) hipLaunchKernelGGL((k_window_wave2<4, false, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
-        else hipLaunchKernelGGL((k_window_wave2<4, false>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
+        else hipLaunchKernelGGL((k_window_wave2<3, false>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
     }
     else hipLaunchKernelGGL(k_window_wave, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
     if (e1) K2R_HIP(hipEventRecord(e1, 0));
@@ -1214,7 +1229,7 @@ extern "C" int dcdf_chunk_fill_window(const dcdf_chunk* h, const dcdf_cube* cube
     K2R_HIP(d_o.alloc(wt * wr * wc * es));
     if (wave_kernel_ok(h)) {
         std::vector<WinItem> items;
-        window_items(0, c, 0, items);
+        window_items(0, c, 0, items, node_kernel_ok(h));
         const int rc = launch_window_items(d_ref, items, d_o.p, out_dtype, nullptr, nullptr, node_kernel_ok(h), h->narrow32);
         if (rc != DCDF_OK) return rc;
     } else {
@@ -1289,20 +1304,20 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         Q.upper = std::max(lower[q], upper[q]);
         const uint64_t cells = (uint64_t)(c.bottom - c.top) * (c.right - c.left);
         if (cells == 0) continue;
-        const uint32_t ncb = ((c.right + 31u) >> 5) - (c.left >> 5);
+        const uint32_t ncb = (c.right - c.left + 63u) >> 6;
         for (uint32_t i = c.start; i < c.end; i++) {
             if (node_wise && !chunks[q]->search_quirk[i]) {
                 if (witems.size() + 4096 > 0xffffff00u) return DCDF_ERR_CAPACITY;
                 items.push_back(SearchItem{(uint32_t)q, i, 0, (uint32_t)witems.size(), ncb});
-                for (uint32_t r = c.top & ~31u; r < c.bottom; r += 32)
-                    for (uint32_t cc = c.left & ~31u; cc < c.right; cc += 32) {
+                for (uint32_t r = c.top; r < c.bottom; r += 64)
+                    for (uint32_t cc = c.left; cc < c.right; cc += 64) {
                         WinItem it{};
                         it.chunk = Q.chunk;
                         it.inst = i;
-                        it.top = (uint16_t)std::max(r, c.top);
-                        it.bottom = (uint16_t)std::min(r + 32, c.bottom);
-                        it.left = (uint16_t)std::max(cc, c.left);
-                        it.right = (uint16_t)std::min(cc + 32, c.right);
+                        it.top = (uint16_t)r;
+                        it.bottom = (uint16_t)std::min(r + 64, c.bottom);
+                        it.left = (uint16_t)cc;
+                        it.right = (uint16_t)std::min(cc + 64, c.right);
                         witems.push_back(it);
                         sx.push_back(SearchExtra{Q.lower, Q.upper});
                     }
@@ -1334,7 +1349,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
             K2R_HIP(hipMemcpy(d_witems.p, witems.data(), witems.size() * sizeof(WinItem), hipMemcpyHostToDevice));
             K2R_HIP(d_sx.alloc(sx.size() * sizeof(SearchExtra)));
             K2R_HIP(hipMemcpy(d_sx.p, sx.data(), sx.size() * sizeof(SearchExtra), hipMemcpyHostToDevice));
-            K2R_HIP(d_wbits.alloc((size_t)nw * 128));  // (every word is written by the walk: nothing to clear)
+            K2R_HIP(d_wbits.alloc((size_t)nw * 512));  // (every word is written by the walk: nothing to clear)
         }
         K2R_HIP(d_counts.alloc(items.size() * 4));
         EventPair ev;
@@ -1349,7 +1364,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
                 hipLaunchKernelGGL((k_window_wave2<4, false, true, int32_t>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
                                    d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
             else
-                hipLaunchKernelGGL((k_window_wave2<4, false, true>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
+                hipLaunchKernelGGL((k_window_wave2<3, false, true>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
                                    d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
             hipLaunchKernelGGL(k_search_count, dim3((ni + 63) / 64), dim3(64), 0, 0, d_wbits.as<uint32_t>(), d_items.as<SearchItem>(),
                                d_qs.as<WinQuery>(), ni, d_counts.as<uint32_t>());
@@ -1464,7 +1479,7 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
         std::vector<WinItem> items;
         for (size_t q = 0; q < nq; q++) {
             const dcdf_cube c{qs[q].start, qs[q].end, qs[q].top, qs[q].bottom, qs[q].left, qs[q].right};
-            window_items(qs[q].chunk, c, qs[q].out_off, items);
+            window_items(qs[q].chunk, c, qs[q].out_off, items, all_node);
         }
         rc = launch_window_items(d_refs, items, d_o.p, (int32_t)DCDF_I64, ev.e0, ev.e1, all_node, all_narrow);
         if (rc != DCDF_OK) return rc;
