@@ -23,8 +23,8 @@ struct dcdf_chunk {
     size_t len = 0;
     DevBuf d_bytes, d_descs;
     // k = 2, sidelen 32..256: for every instant the walk's state at each node of side 16 (k_top_table, built at open): the wave
-    // walks of fill_window / search start there instead of at the root (an item never leaves one square of the 32-grid: it
-    // begins with that square's four entries)
+    // walks of fill_window / search start there instead of at the root (an item begins with
+    // the entries of the squares it meets)
     DevBuf d_top, d_top_mm;
     uint32_t top_g = 0;  // squares per side (sidelen / 16), 0 = no table
     // every stored value of every instant lies in [-2^30, 2^30) (from the root extremes): the query walks then run on 32-bit
@@ -536,7 +536,7 @@ struct WaveQ2T {
 };
 typedef WaveQ2T<int64_t> WaveQ2;
 // What a search item adds to its WinItem (search = the same walk; instead of storing a cell it tests lower <= v <= upper and
-// sets the cell's bit in the sub-window's own 32-word bitmap -- word = row - top, bit = column - left -- at out[item * 32];
+// sets the cell's bit in the item's own bitmap -- 64 rows x 2 words: word = 2 * (row - top) + (column - left) / 32 -- at out[item * 128];
 // no two waves share a word, so there is nothing atomic about it and nothing to clear beforehand).
 struct SearchExtra {
     int64_t lower, upper;
@@ -890,7 +890,7 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table, TopMM* __restrict__ table_mm
         hi = cs == 16 ? hi : hi + tot;
     }
 }
-// counts of the (query, instant) items the wave walk marked: one thread each over the item's sub-window bitmaps
+// counts of the (query, instant) items the wave walk marked: one thread each over the bitmaps of the item's pieces
 __global__ void __launch_bounds__(64)
 k_search_count(const uint32_t* __restrict__ wbits, const SearchItem* __restrict__ items, const WinQuery* __restrict__ qs, uint32_t n,
                uint32_t* __restrict__ counts) {
@@ -1283,7 +1283,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     dedup_chunks(chunks, nq, cidx, uniq);
     std::vector<WinQuery> qs(nq);
     std::vector<SearchItem> items;
-    // k = 2 chunks: the wave-cooperative walk of fill_window marks the matches (one wave per 32 x 32 sub-window and
+    // k = 2 chunks: the wave-cooperative walk of fill_window marks the matches (one wave per piece of <= 64 x 64 cells and
     // instant, each into its own 32-word bitmap); other arities -- and the instants of dcdf_chunk::search_quirk -- keep the
     // per-thread pruned descent and its flat per-item bitmap
     bool node_wise = std::getenv("K2R_SEARCH_DFS") == nullptr;  // (diagnostics: A/B against the per-thread descent)
