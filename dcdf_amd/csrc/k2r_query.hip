@@ -1284,7 +1284,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     std::vector<WinQuery> qs(nq);
     std::vector<SearchItem> items;
     // k = 2 chunks: the wave-cooperative walk of fill_window marks the matches (one wave per piece of <= 64 x 64 cells and
-    // instant, each into its own 32-word bitmap); other arities -- and the instants of dcdf_chunk::search_quirk -- keep the
+    // instant, each into its own 128-word bitmap); other arities -- and the instants of dcdf_chunk::search_quirk -- keep the
     // per-thread pruned descent and its flat per-item bitmap
     bool node_wise = std::getenv("K2R_SEARCH_DFS") == nullptr;  // (diagnostics: A/B against the per-thread descent)
     for (const dcdf_chunk* u : uniq) node_wise = node_wise && node_kernel_ok(u);
