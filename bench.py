@@ -99,6 +99,11 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # stdout carries ONE line, the JSON result: whatever libraries write to file descriptor 1 meanwhile (gloo announces its
+    # connections there) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -339,8 +344,8 @@ def main():
             "cpu_baseline": cpu,
             "gather": gather,
         }
-        print(json.dumps(line))
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
