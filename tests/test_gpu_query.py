@@ -226,6 +226,21 @@ def test_wide_value_chunks_take_the_64_bit_walk(dc, kind):
         assert got == brute(a, s, e, t, bo, l, r, lo, hi)
 
 
+def test_windows_larger_than_one_piece(dc):
+    """Windows beyond 64 x 64 cells are cut into pieces from their origin (one wave item each); search results of the pieces
+    are stitched in (instant, row, col) order."""
+    from dcdf_amd import synth
+    a = synth.cells(0xDCDF0007, 0, 5, 0, 256, 0, 256, np.int32)
+    c = dc.Chunk.build(a).data
+    rng = np.random.default_rng(11)
+    for (t, bo, l, r) in [(0, 256, 0, 256), (3, 203, 17, 207), (60, 125, 1, 256), (0, 65, 190, 255), (100, 229, 64, 129)]:
+        np.testing.assert_array_equal(c.fill_window(dc.Cube(1, 4, t, bo, l, r)), a[1:4, t:bo, l:r])
+        lo = int(rng.integers(int(a.min()), int(a.max()) - 300)); hi = lo + 300
+        got = c.iter_search(dc.Cube(1, 4, t, bo, l, r), lo, hi)
+        want = sorted(brute(a, 1, 4, t, bo, l, r, lo, hi))
+        assert [tuple(x) for x in got.tolist()] == want  # the reference's order: instant, row, col
+
+
 def test_suggest_fraction_golden_and_random(dc):  # fixed.rs:96-159, tests fixed.rs:311-401
     import json, os
     G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
