@@ -603,9 +603,20 @@ K2R_HD bool guard_ok(EX& ex, bool ok, uint32_t code, uint32_t inst, uint32_t tid
 // failed and its output discarded) -- no branch, no divergence
 template <class EX>
 K2R_HD uint32_t guard_pos(EX& ex, uint32_t pos, uint32_t span, uint32_t limit, uint32_t code) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(K2R_GUARD_FULL)
+    // Release build of the GPU kernel: the position is clamped into [0, limit - span] with ONE instruction (median of
+    // pos, 0 and the wave-uniform bound), which is all the memory safety needs; the recording form below cost five
+    // per site (~7 % of the kernel's instructions).  A logic error then shows up as wrong bytes (parity tests) instead
+    // of ST_INTERNAL; the recording form still runs in the simulator suite and in -DK2R_GUARD_FULL builds.
+    int32_t r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"((int32_t)pos), "s"((int32_t)limit - (int32_t)span));
+    (void)ex; (void)code;
+    return (uint32_t)r;
+#else
     const bool ok = pos + span <= limit;
     ex.gfail |= ok ? 0u : (1u << (code & 31u));
     return ok ? pos : 0u;
+#endif
 }
 template <class EX>
 K2R_HD void guard_flush(EX& ex) {
