@@ -414,7 +414,9 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
     out->node = header(2);
     out->node.push_back(5);  // NODE_SUPERCHUNK
     out->node += body;
-    out->size_self = 7 + body.size();  // superchunk.rs:652-670
+    // Superchunk::size() (superchunk.rs:652-670): header + every field save_to writes EXCEPT the `encoding` byte of
+    // superchunk.rs:692 -- the reference's formula leaves it out, and a drop-in reports what the reference reports
+    out->size_self = 7 + body.size() - 1;
     out->size = out->size_self + size_external + sizes;
     out->external = (uint32_t)external.size();
     return DCDF_OK;

@@ -164,7 +164,9 @@ def superchunk_build(a, levels, k, store, fractional_bits=0, round_=False):
     body += external_cid + struct.pack(">I", 0)
     body += O.dac_serialize(maxs) + O.dac_serialize(mins)
     obj = header(NODE_MMSTRUCT3) + bytes([NODE_SUPERCHUNK]) + body
-    size_self = HEADER_SIZE + len(body)  # superchunk.rs:652-670 (== serialized length minus the node tag)
+    # Superchunk::size(), superchunk.rs:652-670: the formula lists every field save_to writes except the one `encoding` byte
+    # of superchunk.rs:692, so it is one less than header + body (tests/test_oracle_superchunk.py derives it term by term)
+    size_self = HEADER_SIZE + len(body) - 1
     stats = {"size_self": size_self, "size": size_self + size_external + sum(sizes), "elided": n_elided, "local": 0,
              "external": len(external), "snapshots": n_snap, "logs": n_logs, "references": references, "links": external}
     return obj, stats

@@ -50,6 +50,7 @@ def test_reference_fixture_shapes(dc):
     assert check(dc, a, [3, 1])["elided"] == 64                                         # no_subchunks_coarse
     st = check(dc, array_n(16), [2, 2])                                                 # external_subchunks: 16 refs, 4 links
     assert len(st["links"]) == 4 and st["elided"] == 0
+    assert st["size_self"] == 3871  # Superchunk::size() term by term (tests/test_oracle_superchunk.py); check() compared b.size with it
     st = check(dc, array_n(17), [2, 3])                                                 # mixed_subchunks
     assert st["elided"] == 8 and sum(r is not None for r in st["references"]) == 8
     e = np.zeros((100, 16, 16), dtype=np.int64) + np.arange(100)[:, None, None]
