@@ -61,6 +61,12 @@ def parse_args(argv=None):
     ap.add_argument("--verify", type=int, default=4, help="chunks compared byte-for-byte with the oracle (untimed)")
     ap.add_argument("--no-gather", action="store_true", help="skip the host-side gather + SHA-256 (profiling runs)")
     ap.add_argument("--pad-elems", type=int, default=0, help="config1: extra elements between consecutive chunks in HBM")
+    ap.add_argument("--dataset", choices=["model", "noise"], default="model",
+                    help="model: the SURVEY 8(d) value model (default, the headline workload).  noise: iid U[0, 2^30) cells -- the "
+                         "adversarial set of SURVEY 8(d): every instant's Snapshot wins chunk.rs:62, i.e. the general (re-reading) "
+                         "emission path and one-instant blocks; a throughput figure for that path, never the headline")
+    ap.add_argument("--host-sample", type=int, default=48, help="chunks pushed through the host-buffer entry point for the "
+                    "PCIe-inclusive end-to-end figure (0 = skip)")
     return ap.parse_args(argv)
 
 
@@ -76,11 +82,37 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # Poll ALL children: if any rank dies, the others would sit in a collective until it times out -- end them at once
+    # (this parent never touches the GPU, and the children are fresh processes of its own).
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        print("bench.py: rank %d exited with code %s; stopping the other ranks" % (failed, procs[failed].returncode), file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        return 1
+    reader.join(timeout=10)
+    sys.stdout.write((chunks[0] if chunks else b"").decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return max(abs(p.returncode) for p in procs)
 
 
 def source_sha():
@@ -178,6 +210,11 @@ def main():
         scaling = "strong"
         workload = ("configs[2]: %dx%dx%d %s raster, seed 0xDCDF0003, tiled into %d [<=32,256,256] chunks; %d of them on "
                     "this GPU" % (args.extent, args.extent, args.days, args.dtype, n_global, n))
+    if args.dataset == "noise":
+        g = torch.Generator(device="cuda")
+        g.manual_seed(0xDCDF0006 + rank)
+        flat.copy_(torch.randint(0, 1 << 30, (flat.numel(),), generator=g, device="cuda", dtype=torch.int64).to(tdt))
+        workload += "; cells replaced by iid U[0, 2^30) noise (--dataset noise)"
     torch.cuda.synchronize()
     if args.dtype in ("f32", "f64"):  # the same integers as exact multiples of 2^-fbits in floating point (|v| < 2^24)
         fb = args.fbits
@@ -285,21 +322,52 @@ def main():
             full = [d for d in data if d.shape[0] == T]
             m = min(args.cpu_sample, len(full))
             sample = torch.stack(full[:m]).cpu().numpy()
-            sec, tb, _ = O.bench_build(sample)
+            native = O.native_lib() is not None  # rebuilt -O3 -march=native on THIS host; else the portable -O3 build
+            sec, tb, _ = O.bench_build(sample, native=native)
             cpu = {"value": sample.size / sec, "unit": "cells/s", "cores": 1, "kind": "port",
                    "sample": "first %d of the %d [%d,%d,%d] %s chunks of this workload (%.1f s); C++ restatement of the Rust "
-                             "reference (no Rust toolchain), built -O3 without -march=native, serial like "
-                             "superchunk.rs:166-188" % (m, n, T, S, S, args.dtype, sec)}
-            # the same port with one chunk per task on every host core (the reference itself is serial)
+                             "reference (no Rust toolchain), built -O3 %s, serial like "
+                             "superchunk.rs:166-188" % (m, n, T, S, S, args.dtype, sec,
+                                                         "-march=native on this host" if native else "without -march=native")}
+            # the same port with one chunk per task on every host core (the reference itself is serial);
+            # rounds of 2 tasks per thread until at least 2.5 s have been measured
             from concurrent.futures import ThreadPoolExecutor
             nthr = max(1, min(16, len(os.sched_getaffinity(0))))  # a one-GPU box's CPU share is 16 cores
             reps = [sample[i % m:i % m + 1] for i in range(2 * nthr)]
+            done_cells, rounds = 0, 0
             w0 = time.perf_counter()
             with ThreadPoolExecutor(nthr) as ex:
-                list(ex.map(O.bench_build, reps))  # ctypes releases the GIL inside the call
+                while time.perf_counter() - w0 < 2.5:
+                    list(ex.map(lambda r: O.bench_build(r, native=native), reps))  # ctypes releases the GIL inside the call
+                    done_cells += sum(r.size for r in reps)
+                    rounds += 1
             wall = time.perf_counter() - w0
-            cpu["all_cores"] = {"value": sum(r.size for r in reps) / wall, "unit": "cells/s", "cores": nthr,
-                                "sample": "%d chunk builds on %d threads (%.1f s)" % (len(reps), nthr, wall)}
+            cpu["all_cores"] = {"value": done_cells / wall, "unit": "cells/s", "cores": nthr,
+                                "sample": "%d chunk builds on %d threads (%.1f s)" % (rounds * len(reps), nthr, wall)}
+
+    # ---- end to end through the host-buffer entry point ("pinned H2D + D2H gather"), rank 0, N = 1 --------
+    # dcdf_chunk_build_batch on tiles in HOST memory: staging, H2D, the same kernel, D2H of the bytes -- PCIe inclusive.  A
+    # bounded sample of the same chunks; reported under its own key, never `value`.
+    end_to_end = None
+    if rank == 0 and world == 1 and args.host_sample > 0:
+        import ctypes as C
+        from dcdf_amd.chunk import _desc
+        hs = [data[c].cpu().numpy() for c in range(min(args.host_sample, n))]
+        hd = (L.TileDesc * len(hs))()
+        for i, a in enumerate(hs):
+            hd[i] = _desc(a, fb, False)
+        best = None
+        for _ in range(3):
+            res = C.POINTER(L.Encoded)()
+            h0 = time.perf_counter()
+            L.check(L.lib().dcdf_chunk_build_batch(hd, C.c_size_t(len(hs)), 2, L.MEM_HOST, C.byref(res)), "chunk_build_batch")
+            dt = time.perf_counter() - h0
+            L.lib().dcdf_free_encoded(res, C.c_size_t(len(hs)))
+            best = dt if best is None else min(best, dt)
+        hcells = sum(a.size for a in hs)
+        end_to_end = {"entry": "dcdf_chunk_build_batch, tiles and results in host memory (staging + H2D + kernel + D2H)",
+                      "value": hcells / best, "unit": "cells/s", "input_GB_per_s": hcells * esz / best / 1e9,
+                      "sample": "first %d chunks of this workload, best of 3 (%.3f s)" % (len(hs), best)}
 
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
@@ -309,7 +377,7 @@ def main():
         # when that profile was taken on this workload with these kernel sources
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        key = "%s/%s/n%d/w%d" % (args.workload, args.dtype, n, world)
+        key = "%s/%s/n%d/w%d%s" % (args.workload, args.dtype, n, world, "" if args.dataset == "model" else "/" + args.dataset)
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf))
@@ -342,6 +410,7 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes, "scope": "rank 0's GPU, HIP events around the encode kernel",
                          "source_sha": source_sha()},
             "cpu_baseline": cpu,
+            "end_to_end_host_buffers": end_to_end,
             "gather": gather,
         }
         sys.stdout.flush()

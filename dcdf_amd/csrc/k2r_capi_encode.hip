@@ -83,17 +83,11 @@ struct dcdf_encoder {
     }
 };
 
-// smallest H with k^H >= max(rows, cols) (snapshot.rs:118-119; the float formula is exact for every size this library accepts)
+// depth and sidelen of a tile's tree, by the reference's own f64 formula (k2r_runtime.h ref_levels)
 static uint32_t depth_for(uint32_t rows, uint32_t cols, uint32_t k, uint64_t* sidelen) {
     const uint64_t m = std::max(rows, cols);
-    uint64_t s = 1;
-    uint32_t h = 0;
-    while (s < m) {
-        s *= k;
-        h++;
-    }
-    *sidelen = s;
-    return h;
+    *sidelen = ref_sidelen(m, k);
+    return ref_levels(m, k);
 }
 constexpr uint64_t kGenericMaxSidelen = 1024;  // universal kernel: level arrays in HBM scratch, ~77 B per node
 
@@ -784,7 +778,7 @@ extern "C" const char* dcdf_strerror(int code) {
         case DCDF_ERR_BOUNDS: return "query out of bounds";
         case DCDF_ERR_TOO_MANY_LOGS: return "too many logs in one block (block.rs:27-32)";
         case DCDF_ERR_FORMAT: return "malformed encoded chunk";
-        case DCDF_ERR_UNSUPPORTED: return "unsupported: sidelen above 1024 outside the fused kernel (k = 2, sidelen 8..256)";
+        case DCDF_ERR_UNSUPPORTED: return "unsupported: sidelen above 1024 (universal kernel's limit; the fused kernel covers k = 2, sidelen 16..256)";
         case DCDF_ERR_NO_DEVICE: return "no usable gfx950 device / HIP failure";
         case DCDF_ERR_NOMEM: return "out of memory";
         case DCDF_ERR_CAPACITY: return "result buffer too small";

@@ -1,4 +1,5 @@
-// k2r_encode.h -- fused Heuristic K^2-Raster chunk encoder (k = 2, sidelen 8..256).
+// k2r_encode.h -- fused Heuristic K^2-Raster chunk encoder (k = 2; built and dispatched for sidelen 16..256, sidelen 8 goes to
+// the universal kernel k2r_generic.hip; the simulator suite still instantiates sidelen 8).
 //
 // Replaces, for one tile, the whole of `Chunk::build` + `Chunk::write_to`
 // (reference chunk.rs:42-96,235-243; snapshot.rs:108-156; log.rs:112-165; dac.rs:96-132;
@@ -39,7 +40,7 @@ namespace k2r {
 
 template <int LOG2S>
 struct EncCfg {
-    static_assert(LOG2S >= 3 && LOG2S <= 8, "fast path covers sidelen 8..256");
+    static_assert(LOG2S >= 3 && LOG2S <= 8, "kernel body written for sidelen 8..256 (the library dispatches 16..256)");
     static constexpr int H = LOG2S;  // tree height; cells are height 0
     static constexpr int S = 1 << LOG2S;
     static constexpr int NBLK = 1 << (2 * (LOG2S - 3));  // 8x8 blocks in the tile

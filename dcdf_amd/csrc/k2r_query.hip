@@ -1034,9 +1034,8 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
         };
         for (const InstDesc& d : c->descs) {
             if (d.k < 2 || d.k > 255 || d.rows == 0 || d.cols == 0) return DCDF_ERR_FORMAT;
-            uint64_t side = 1;  // snapshot.rs:118-119: the smallest power of k covering the tile
-            while (side < std::max(d.rows, d.cols)) side *= d.k;
-            if (d.sidelen != side) return DCDF_ERR_FORMAT;
+            // snapshot.rs:118-119: k^ceil(ln(max)/ln(k)) in f64 -- what the reference writes (625 for a 125-wide tile with k = 5)
+            if (d.sidelen != ref_sidelen(std::max(d.rows, d.cols), d.k)) return DCDF_ERR_FORMAT;
             if (d.T.k != 4 || (d.is_log && d.E.k != 4)) return DCDF_ERR_FORMAT;  // bitmap.rs:69,130
             const uint64_t internal = ones(d.T);
             const uint64_t visited = 1 + (uint64_t)d.k * d.k * internal;          // snapshot.rs:177: four children per internal node

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <mutex>
 #include <string>
 
@@ -9,6 +10,20 @@
 #include "k2r_common.h"
 
 namespace k2r {
+
+// Tree depth as the reference computes it: ceil(ln(m) / ln(k)) in f64 (snapshot.rs:118-119, log.rs:124-125,
+// superchunk.rs:98-101).  NOT always the smallest H with k^H >= m: ln(125)/ln(5) = 3.0000000000000004, so a 125-wide tile
+// with k = 5 gets 4 levels and sidelen 625 (likewise k = 6, m = 216 -> 1296); a drop-in has to build and accept the same tree.
+inline uint32_t ref_levels(uint64_t m, uint32_t k) {
+    if (m <= 1) return 0;
+    const double e = std::ceil(std::log((double)m) / std::log((double)k));
+    return e > 0 ? (uint32_t)e : 0u;
+}
+inline uint64_t ref_sidelen(uint64_t m, uint32_t k) {
+    uint64_t s = 1;
+    for (uint32_t i = ref_levels(m, k); i > 0; i--) s *= k;
+    return s;
+}
 
 struct Runtime {
     bool ok = false;

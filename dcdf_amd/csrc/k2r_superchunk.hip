@@ -199,15 +199,7 @@ int dac_bytes(const std::vector<int64_t>& v, std::string& out) {
     K2R_HIP(hipMemcpy(&out[0], d_out.p, len, hipMemcpyDeviceToHost));
     return DCDF_OK;
 }
-uint32_t levels_needed(uint64_t side, int k) {  // superchunk.rs:98-101 (ceil(log_k(side)), exact for our sizes)
-    uint32_t h = 0;
-    uint64_t s = 1;
-    while (s < side) {
-        s *= (uint64_t)k;
-        h++;
-    }
-    return h;
-}
+uint32_t levels_needed(uint64_t side, int k) { return ref_levels(side, (uint32_t)k); }  // superchunk.rs:98-101 (f64 formula)
 
 // One Superchunk::build over the DEVICE view `buf` (superchunk.rs:88-270).
 int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size_t n_levels, Level* out) {

@@ -36,7 +36,7 @@ enum {
     DCDF_ERR_BOUNDS = -5,        /* query outside the chunk                 mmarray.rs:218-229     */
     DCDF_ERR_TOO_MANY_LOGS = -6, /* unreachable through build (254 cap)     block.rs:27-32         */
     DCDF_ERR_FORMAT = -7,        /* malformed encoded chunk on open         chunk.rs:247-266       */
-    DCDF_ERR_UNSUPPORTED = -8,   /* sidelen > 1024 outside k = 2, sidelen 8..256   */
+    DCDF_ERR_UNSUPPORTED = -8,   /* sidelen > 1024 (fused kernel: k = 2, sidelen 16..256) */
     DCDF_ERR_NO_DEVICE = -9,     /* no gfx950 device / HIP runtime failure                         */
     DCDF_ERR_NOMEM = -10,
     DCDF_ERR_CAPACITY = -11,     /* result buffer too small (search): *n holds the needed count    */

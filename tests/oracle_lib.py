@@ -28,6 +28,24 @@ def lib():
     return _lib
 
 
+_native = None
+
+
+def native_lib():
+    """The oracle rebuilt -O3 -march=native on THIS host (timing only: bench.py's cpu_baseline); None if that fails."""
+    global _native
+    if _native is None:
+        try:
+            import tempfile
+            out = tempfile.mkdtemp(prefix="k2r_oracle_native_")  # never in-tree: a -march=native .so must not travel to another host
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", "OUT=" + out],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _native = C.CDLL(os.path.join(out, "libk2r_oracle_native.so"))
+        except Exception:
+            _native = False
+    return _native or None
+
+
 class OracleError(Exception):
     def __init__(self, code):
         super().__init__("oracle error %d" % code)
@@ -298,11 +316,13 @@ def sidelen(rows, cols, k=2):
     return int(lib().orc_sidelen(C.c_uint32(rows), C.c_uint32(cols), k))
 
 
-def bench_build(a4, k=2):
-    """a4: [n_chunks, instants, rows, cols] contiguous.  Returns (seconds, total_bytes, fnv)."""
+def bench_build(a4, k=2, native=False):
+    """a4: [n_chunks, instants, rows, cols] contiguous.  Returns (seconds, total_bytes, fnv).  native: use the
+    -march=native build of this host when it can be made (same code, same results)."""
     a4 = np.ascontiguousarray(a4)
     sec, tb, h = C.c_double(), C.c_uint64(), C.c_uint64()
-    _check(lib().orc_bench_build(C.c_void_p(a4.ctypes.data), ENC[a4.dtype], C.c_uint32(a4.shape[0]),
+    L = (native_lib() if native else None) or lib()
+    _check(L.orc_bench_build(C.c_void_p(a4.ctypes.data), ENC[a4.dtype], C.c_uint32(a4.shape[0]),
                                  C.c_uint32(a4.shape[1]), C.c_uint32(a4.shape[2]), C.c_uint32(a4.shape[3]), k,
                                  C.byref(sec), C.byref(tb), C.byref(h)))
     return sec.value, tb.value, h.value

@@ -116,6 +116,27 @@ def test_other_k(dc, k):
     assert got == want
 
 
+def test_depth_follows_the_reference_float_formula(dc):
+    """snapshot.rs:118-119 takes ceil(ln(side)/ln(k)) in f64: a 125-wide tile with k = 5 gets FOUR levels (sidelen 625), not
+    the three an exact power search finds (ln 125 / ln 5 = 3.0000000000000004).  Encode, open and query must agree with it."""
+    rng = np.random.default_rng(125)
+    a = rng.integers(-50, 50, size=(5, 125, 125)).astype(np.int64)
+    a[2] = a[1]
+    a[3, :60] = a[1, :60] + 3
+    ref = O.chunk_build(a, k=5)
+    assert ref[6 + 1 + 1 + 8:6 + 1 + 1 + 12] == (625).to_bytes(4, "big")  # the first Snapshot's sidelen field (snapshot.rs:48-58)
+    assert_same(dc, [a, a[:, :125, :100], a[:, :124, :124]], k=5)
+    c = dc.Chunk.build(a, k=5).data  # Chunk::build on the GPU, then dcdf_chunk_open of those bytes
+    assert c.write_to() == ref
+    np.testing.assert_array_equal(c.fill_window(dc.Cube(0, 5, 0, 125, 0, 125)), a)
+    oc = O.Chunk(ref)
+    assert c.get(3, 124, 124) == oc.get(3, 124, 124) == int(a[3, 124, 124])
+    got = set(map(tuple, c.iter_search(dc.Cube(1, 5, 3, 120, 7, 125), -5, 9).tolist()))
+    assert got == set(map(tuple, oc.search(1, 5, 3, 120, 7, 125, -5, 9).tolist()))
+    r = dc.build_batch([np.zeros((1, 216, 216), dtype=np.int32)], k=6)[0]  # same formula: 4 levels, sidelen 1296 > 1024
+    assert isinstance(r, Exception) and r.code == -8
+
+
 def test_superchunk_fixture_subchunks(dc):
     """mmstruct.rs:463-479: testing::array(17) as [100,17,17], levels [1,2,2], k = 2 -> superchunk.rs:119-181 cuts it into
     4x4 sub-chunks, ragged 4x1 / 1x4 ones along the edges and a 1x1 corner; every one of them must encode."""
