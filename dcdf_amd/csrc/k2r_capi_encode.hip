@@ -13,6 +13,9 @@
 #include <thread>
 #include <vector>
 
+#include <cstring>
+#include <queue>
+
 #include "k2r_launch.h"
 #include "k2r_runtime.h"
 
@@ -46,6 +49,105 @@ static uint32_t sidelen_log2(uint32_t rows, uint32_t cols) {  // snapshot.rs:118
 }
 static size_t elem_size(int dtype) { return (dtype == DCDF_I32 || dtype == DCDF_F32) ? 4 : 8; }
 
+// ---- speculative halves: which tiles of a class to encode as two work items --------------------------------------------
+// A chunk is the unit of work (its instants are sequential) and a workgroup owns a CU, so when a GPU holds only a few
+// chunks per CU the last round of the work queue leaves CUs idle: 384 chunks on 256 CUs take two chunk-times, not 1.5.
+// Encoding the chunks at the END of the (longest-first) queue as two halves each fills that round.  The decision is a
+// simulation of the queue: `inst` = instants per tile in queue order, `wgs` = resident workgroups; candidates: no split, the
+// last (n mod wgs) tiles, all tiles; a split has to beat the unsplit makespan by 8 % (it costs one priming pass per second
+// half and the splice).  K2R_SPLIT=0 disables, K2R_SPLIT=all forces every tile (tests).
+static uint64_t queue_makespan(const std::vector<uint32_t>& cost, uint32_t wgs) {
+    std::vector<uint32_t> c(cost);
+    std::stable_sort(c.begin(), c.end(), [](uint32_t a, uint32_t b) { return a > b; });
+    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> free_at;
+    for (uint32_t w = 0; w < wgs; w++) free_at.push(0);
+    uint64_t end = 0;
+    for (uint32_t x : c) {
+        const uint64_t t = free_at.top() + x;
+        free_at.pop();
+        free_at.push(t);
+        end = std::max(end, t);
+    }
+    return end;
+}
+static size_t plan_split(const std::vector<uint32_t>& inst, uint32_t wgs) {
+    const size_t n = inst.size();
+    const char* env = std::getenv("K2R_SPLIT");
+    auto splittable = [&](size_t ns) {  // the last ns tiles, shrunk to those with at least 4 instants
+        while (ns > 0 && inst[n - ns] < 4) ns--;
+        size_t ok = 0;
+        for (size_t q = n - ns; q < n; q++) ok += inst[q] >= 4;
+        return ok == ns ? ns : (size_t)0;
+    };
+    if (env && std::strcmp(env, "0") == 0) return 0;
+    if (env && std::strcmp(env, "all") == 0) return splittable(n);
+    auto makespan = [&](size_t ns) {
+        std::vector<uint32_t> cost;
+        for (size_t q = 0; q < n; q++) {
+            if (q + ns < n) cost.push_back(inst[q]);
+            else {
+                cost.push_back(inst[q] / 2);
+                cost.push_back(inst[q] - inst[q] / 2 + 1);
+            }
+        }
+        return queue_makespan(cost, wgs);
+    };
+    const uint64_t base = makespan(0);
+    size_t best = 0;
+    uint64_t best_t = base;
+    for (size_t cand : {n % wgs, n}) {
+        const size_t ns = splittable(cand);
+        if (ns == 0) continue;
+        const uint64_t t = makespan(ns);
+        if (t < best_t) {
+            best_t = t;
+            best = ns;
+        }
+    }
+    return (best_t * 100 <= base * 92) ? best : 0;
+}
+
+// Splices the two halves of a split tile: pairs[2 j] = the tile (first half, in its own slot), pairs[2 j + 1] = the
+// continuation's item.  Valid when the first half holds exactly one block (what the continuation assumed): its bytes are
+// appended, block 0's count byte (chunk offset 6, block.rs:89) and n_blocks (chunk.rs:238) are patched, the counters added.
+// Otherwise ST_RESPLIT (the host re-encodes the tile whole); an error of either half is the tile's error.
+__global__ void __launch_bounds__(1024) k_stitch(const uint32_t* __restrict__ pairs, const TileArgs* __restrict__ args,
+                                                  TileResult* __restrict__ res) {
+    const uint32_t a = pairs[2 * blockIdx.x], b = pairs[2 * blockIdx.x + 1];
+    const int32_t sa = res[a].status, sb = res[b].status;
+    const uint64_t la = res[a].len, lb = res[b].len;
+    int32_t st = ST_OK;
+    if (sa != ST_OK) st = sa;
+    else if (res[a].snapshots != 1) st = ST_RESPLIT;
+    else if (sb != ST_OK) st = sb;
+    else if (la + lb > args[a].out_cap) st = ST_OUT_CAPACITY;
+    if (st == ST_OK) {
+        uint8_t* dst = args[a].out + la;
+        const uint8_t* src = args[b].out;
+        // 16 bytes per thread and step (the source slot is 256-byte aligned; the destination is wherever the first half ended:
+        // global memory takes unaligned vector stores), then the tail
+        typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
+        typedef uint32_t u4a __attribute__((ext_vector_type(4)));
+        const uint64_t nv = lb / 16;
+        for (uint64_t i = threadIdx.x; i < nv; i += blockDim.x) *(u4*)(dst + 16 * i) = *(const u4a*)(src + 16 * i);
+        for (uint64_t i = 16 * nv + threadIdx.x; i < lb; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (st == ST_OK) {
+            args[a].out[6] = (uint8_t)res[b].carry_count;
+            store_be32(args[a].out + 2, 1u + res[b].snapshots);
+            res[a].len = la + lb;
+            res[a].snapshots += res[b].snapshots;
+            res[a].logs += res[b].logs;
+            res[a].stash_logs += res[b].stash_logs;
+        } else {
+            res[a].status = st;
+            res[a].len = 0;
+        }
+    }
+}
+
 // Upper bound of one serialized instant (all values 4 bytes): used when the default slot overflows.
 static uint64_t worst_instant_bytes(uint32_t lg) {
     const uint64_t maxv = ((1ull << (2 * (lg + 1))) - 1) / 3, maxt = ((1ull << (2 * lg)) - 1) / 3;
@@ -68,6 +170,11 @@ struct dcdf_encoder {
     std::vector<size_t> lists_off;     // per class offset (u64 words) into d_lists
     std::vector<uint32_t> grid;
     std::vector<std::unique_ptr<DevBuf>> retry_slots;  // bigger slots for tiles that overflowed
+    // Speculative halves (k2r_encode.h): tiles encoded as two work items, (a) the tile's own TileArgs restricted to the first
+    // instants and (b) an extra TileArgs at index n + j for the rest, spliced by k_stitch inside the timed region.
+    std::vector<std::vector<uint32_t>> class_items;  // per class: the launch order (tile indices and extra indices >= n)
+    std::vector<uint32_t> split_a, split_b;          // pairs (tile, extra item)
+    DevBuf d_pairs, d_out_b;
     // tiles outside the fused kernel's contract (k != 2, sidelen < 8 or > 256): encoded by the universal kernel
     // (k2r_generic.hip); key = k << 8 | H
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> generic_groups;
@@ -194,30 +301,76 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
         a.minmax = e->d_minmax.as<int64_t>() + e->minmax_off[i];
         e->args[i] = a;
     }
-    // per-class launch geometry
+    // per-class launch geometry; which tiles are encoded as two speculative halves (plan_split)
     size_t order_total = 0, lists_total = 0;
+    uint64_t out_b_total = 0;
+    std::vector<uint64_t> out_b_off;
+    e->class_items.resize(e->classes.size());
     for (size_t ci = 0; ci < e->classes.size(); ci++) {
         const EncClass& c = e->classes[ci];
-        const uint32_t nt = (uint32_t)e->class_tiles[ci].size();
+        auto& v = e->class_tiles[ci];
+        // longest chunks first: the tail of the work queue is then made of the short ones
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return tiles[a].instants > tiles[b].instants; });
         const int per_cu = encode_blocks_per_cu(c);
-        uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)rt.cus * (uint64_t)per_cu);
-        if (const char* mw = std::getenv("K2R_MAX_WGS")) g = std::min<uint32_t>(g, (uint32_t)std::max(1, std::atoi(mw)));  // diagnostics
+        uint32_t wgs = (uint32_t)((uint64_t)rt.cus * (uint64_t)per_cu);
+        if (const char* mw = std::getenv("K2R_MAX_WGS")) wgs = std::min<uint32_t>(wgs, (uint32_t)std::max(1, std::atoi(mw)));  // diagnostics
+        std::vector<uint32_t> inst(v.size());
+        for (size_t q = 0; q < v.size(); q++) inst[q] = tiles[v[q]].instants;
+        const size_t ns = plan_split(inst, std::max(1u, wgs));  // the LAST ns tiles of v are split
+        struct Item { uint32_t idx, cost; };
+        std::vector<Item> items;
+        for (size_t q = 0; q < v.size(); q++) {
+            const uint32_t ti = v[q], T = tiles[ti].instants;
+            if (q + ns < v.size()) {
+                items.push_back({ti, T});
+                continue;
+            }
+            const uint32_t m = T / 2, bi = (uint32_t)e->args.size();
+            e->args[ti].inst_end = m;
+            TileArgs b = e->args[ti];
+            b.inst_begin = m;
+            b.inst_end = T;
+            b.out_cap = ((e->slot_cap[ti] * (T - m) + T - 1) / T + 4096 + 255) & ~255ull;
+            out_b_off.push_back(out_b_total);
+            out_b_total += b.out_cap;
+            e->args.push_back(b);
+            e->split_a.push_back(ti);
+            e->split_b.push_back(bi);
+            items.push_back({ti, m});
+            items.push_back({bi, T - m + 1});  // + the priming pass
+        }
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+        for (const Item& it : items) e->class_items[ci].push_back(it.idx);
+        const uint32_t g = (uint32_t)std::min<uint64_t>(items.size(), wgs);
         e->grid.push_back(std::max(1u, g));
         e->order_off.push_back(order_total);
-        order_total += nt;
+        order_total += items.size();
         e->lists_off.push_back(lists_total);
         lists_total += (size_t)e->grid.back() * encode_list_words(c);
+    }
+    if (!e->split_a.empty()) {
+        K2R_HIP(e->d_out_b.alloc(out_b_total));
+        std::vector<uint32_t> pairs;
+        for (size_t j = 0; j < e->split_a.size(); j++) {
+            e->args[e->split_b[j]].out = e->d_out_b.as<uint8_t>() + out_b_off[j];
+            pairs.push_back(e->split_a[j]);
+            pairs.push_back(e->split_b[j]);
+        }
+        K2R_HIP(e->d_pairs.alloc(pairs.size() * 4));
+        K2R_HIP(hipMemcpy(e->d_pairs.p, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+        // the item tables grew
+        e->d_args.release();
+        e->d_results.release();
+        K2R_HIP(e->d_args.alloc(e->args.size() * sizeof(TileArgs)));
+        K2R_HIP(e->d_results.alloc(e->args.size() * sizeof(TileResult)));
     }
     K2R_HIP(e->d_order.alloc(std::max<size_t>(order_total, 1) * 4));
     K2R_HIP(e->d_queue.alloc(std::max<size_t>(e->classes.size(), 1) * 4));
     K2R_HIP(e->d_lists.alloc(std::max<size_t>(lists_total, 1) * 8));
-    for (size_t ci = 0; ci < e->classes.size(); ci++) {
-        // longest chunks first: the tail of the work queue is then made of the short ones
-        auto& v = e->class_tiles[ci];
-        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return tiles[a].instants > tiles[b].instants; });
-        K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], v.data(), v.size() * 4, hipMemcpyHostToDevice));
-    }
-    K2R_HIP(hipMemcpy(e->d_args.p, e->args.data(), n * sizeof(TileArgs), hipMemcpyHostToDevice));
+    for (size_t ci = 0; ci < e->classes.size(); ci++)
+        K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], e->class_items[ci].data(), e->class_items[ci].size() * 4,
+                          hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(e->d_args.p, e->args.data(), e->args.size() * sizeof(TileArgs), hipMemcpyHostToDevice));
     *enc_out = e.release();
     return DCDF_OK;
 }
@@ -227,7 +380,7 @@ static int run_classes(dcdf_encoder* e, const std::vector<std::vector<uint32_t>>
     K2R_HIP(hipMemsetAsync(e->d_queue.p, 0, e->d_queue.bytes, e->stream));
     K2R_HIP(hipEventRecord(e->ev0, e->stream));
     for (size_t ci = 0; ci < e->classes.size(); ci++) {
-        uint32_t nt = (uint32_t)e->class_tiles[ci].size();
+        uint32_t nt = (uint32_t)e->class_items[ci].size();
         if (subset) {
             nt = (uint32_t)(*subset)[ci].size();
             if (nt == 0) continue;
@@ -244,6 +397,9 @@ static int run_classes(dcdf_encoder* e, const std::vector<std::vector<uint32_t>>
         L.grid = std::min(e->grid[ci], std::max(1u, nt));
         K2R_HIP(launch_encode(e->classes[ci], L, e->stream));
     }
+    if (!subset && !e->split_a.empty())  // splice the speculative halves (inside the timed region)
+        hipLaunchKernelGGL(k2r::k_stitch, dim3((uint32_t)e->split_a.size()), dim3(1024), 0, e->stream, e->d_pairs.as<uint32_t>(),
+                           e->d_args.as<TileArgs>(), e->d_results.as<TileResult>());
     K2R_HIP(hipEventRecord(e->ev1, e->stream));
     K2R_HIP(hipStreamSynchronize(e->stream));
     if (kernel_ms) K2R_HIP(hipEventElapsedTime(kernel_ms, e->ev0, e->ev1));
@@ -319,6 +475,25 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
         for (int k = 0; k < NPROF; k++)
             std::fprintf(stderr, "k2r-prof %-18s %14llu cyc %5.1f%%\n", names[k], (unsigned long long)acc[k],
                          tot ? 100.0 * (double)acc[k] / (double)tot : 0.0);
+        // per-tile totals: how uneven are the chunks?  (cycles per instant, logs that did not come from the stash)
+        std::vector<double> per;
+        uint64_t logs = 0, stash = 0;
+        for (size_t i = 0; i < n; i++) {
+            uint64_t t = 0;
+            for (int k = 0; k < NPROF; k++) t += e->results[i].prof[k];
+            const uint32_t ni = e->results[i].snapshots + e->results[i].logs;
+            if (ni) per.push_back((double)t / ni);
+            logs += e->results[i].logs;
+            stash += e->results[i].stash_logs;
+        }
+        std::sort(per.begin(), per.end());
+        if (!per.empty()) {
+            double sum = 0;
+            for (double x : per) sum += x;
+            std::fprintf(stderr, "k2r-prof cycles/instant per tile: min %.0f p50 %.0f mean %.0f p90 %.0f p99 %.0f max %.0f | logs %llu from stash %llu\n",
+                         per.front(), per[per.size() / 2], sum / per.size(), per[per.size() * 9 / 10], per[per.size() * 99 / 100],
+                         per.back(), (unsigned long long)logs, (unsigned long long)stash);
+        }
     }
     for (size_t i = 0; i < n; i++)
         if (e->results[i].status == ST_INTERNAL) {
@@ -326,19 +501,28 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
             std::fprintf(stderr, "dcdf_k2r: internal guard tripped on tile %zu: guard bitmask=0x%08x (bit = kGuard* in k2r_encode.h)\n",
                          i, d[0]);
         }
-    // Tiles whose slot was too small: re-encode them alone into worst-case slots (rare; not timed).
+    // Tiles whose slot was too small: re-encode them alone into worst-case slots (rare; not timed).  Tiles whose
+    // speculative halves did not splice: re-encode them whole (which may then turn out too big for the slot: second pass).
+    for (int pass = 0; pass < 2; pass++) {
     std::vector<std::vector<uint32_t>> again(e->classes.size());
-    bool any = false;
+    bool any = false, unsplit = false;
     for (size_t ci = 0; ci < e->classes.size(); ci++)
         for (uint32_t ti : e->class_tiles[ci])
-            if (e->results[ti].status == ST_OUT_CAPACITY) {
-                const dcdf_tile_desc& t = e->desc[ti];
-                const uint64_t cap = 6 + (uint64_t)t.instants * (1 + worst_instant_bytes((uint32_t)e->classes[ci].log2s));
-                std::unique_ptr<DevBuf> b(new DevBuf());
-                K2R_HIP(b->alloc(cap));
-                e->args[ti].out = b->as<uint8_t>();
-                e->args[ti].out_cap = cap;
-                e->retry_slots.push_back(std::move(b));
+            if (e->results[ti].status == ST_OUT_CAPACITY || e->results[ti].status == ST_RESPLIT) {
+                if (e->results[ti].status == ST_OUT_CAPACITY) {
+                    const dcdf_tile_desc& t = e->desc[ti];
+                    const uint64_t cap = 6 + (uint64_t)t.instants * (1 + worst_instant_bytes((uint32_t)e->classes[ci].log2s));
+                    std::unique_ptr<DevBuf> b(new DevBuf());
+                    K2R_HIP(b->alloc(cap));
+                    e->args[ti].out = b->as<uint8_t>();
+                    e->args[ti].out_cap = cap;
+                    e->retry_slots.push_back(std::move(b));
+                }
+                // (a tile that had been split is encoded whole this time -- and from now on: a block boundary in its first
+                // half, or a slot too small, would come back on every run)
+                const bool was_split = e->args[ti].inst_end != 0;
+                e->args[ti].inst_end = 0;
+                unsplit = unsplit || was_split;
                 K2R_HIP(hipMemcpy(e->d_args.as<TileArgs>() + ti, &e->args[ti], sizeof(TileArgs), hipMemcpyHostToDevice));
                 again[ci].push_back(ti);
                 any = true;
@@ -347,10 +531,35 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
         rc = run_classes(e, &again, nullptr);
         if (rc != DCDF_OK) return rc;
         K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
+        if (unsplit) {  // drop the pairs (and extra items) of the tiles that are whole from now on
+            std::vector<uint32_t> pairs, sa, sb;
+            std::vector<uint8_t> gone(e->args.size(), 0);
+            for (size_t j = 0; j < e->split_a.size(); j++) {
+                if (e->args[e->split_a[j]].inst_end == 0) {
+                    gone[e->split_b[j]] = 1;
+                    continue;
+                }
+                sa.push_back(e->split_a[j]);
+                sb.push_back(e->split_b[j]);
+                pairs.push_back(e->split_a[j]);
+                pairs.push_back(e->split_b[j]);
+            }
+            e->split_a.swap(sa);
+            e->split_b.swap(sb);
+            if (!pairs.empty()) K2R_HIP(hipMemcpy(e->d_pairs.p, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+            for (auto& items : e->class_items) {
+                std::vector<uint32_t> keep;
+                for (uint32_t it : items)
+                    if (!gone[it]) keep.push_back(it);
+                items.swap(keep);
+            }
+        }
         // restore the full order lists for a later run()
         for (size_t ci = 0; ci < e->classes.size(); ci++)
-            K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], e->class_tiles[ci].data(),
-                              e->class_tiles[ci].size() * 4, hipMemcpyHostToDevice));
+            K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], e->class_items[ci].data(),
+                              e->class_items[ci].size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!any) break;
     }
     // The universal kernel: tiles outside the fused kernel's shapes, then the tiles the fused kernel declined at run time
     // (a stored value beyond its 2^30 contract: ST_UNSUPPORTED) -- same slot, retried with an exact-size one if need be.

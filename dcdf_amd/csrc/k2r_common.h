@@ -32,6 +32,7 @@ enum : int32_t {
     ST_UNSUPPORTED = -8,
     ST_OUT_CAPACITY = -100,  // internal: output slot too small, host retries with a bigger slot
     ST_INTERNAL = -101,      // an internal consistency guard tripped (bug); TileResult.dbg has the record
+    ST_RESPLIT = -102,       // internal: a chunk encoded as two speculative halves whose assumption failed; the host re-runs it whole
 };
 
 enum : int32_t { ENC_I32 = 4, ENC_I64 = 8, ENC_F32 = 32, ENC_F64 = 64 };
@@ -51,6 +52,11 @@ struct TileArgs {  // one Chunk::build input (device-visible copy of dcdf_tile_d
     uint64_t out_cap;  // bytes
     int64_t* minmax;   // [instants][2] or null
     uint32_t stash_words;  // 0 = default; else caps the LDS words the log stash may use (k2r_encode.h; tests, A/B runs)
+    // Part of a chunk (k2r_encode.h "speculative halves"): instants [inst_begin, inst_end) only; inst_end == 0 means all.
+    // inst_begin > 0 = a continuation: it assumes the chunk's first block is still open at inst_begin, with instant 0 as its
+    // snapshot and inst_begin instants in it, and writes its Logs / Blocks from byte 0 of `out` (no chunk header).
+    uint32_t inst_begin;
+    uint32_t inst_end;
     uint32_t _reserved;
 };
 
@@ -62,7 +68,7 @@ struct TileResult {
     uint32_t stash_logs;  // diagnostic: logs emitted from the LDS stash (no re-read of the input)
     uint64_t len;
     uint32_t dbg[6];  // guard record when status == ST_INTERNAL: count, code, instant, tid, value, limit
-    uint32_t _pad1;
+    uint32_t carry_count;  // continuation: instants of the inherited block (when it closed, or at the end if it never did)
     uint32_t _pad2;
     uint64_t prof[NPROF];  // shader-clock cycles per phase (only filled by -DK2R_PROFILE diagnostic builds)
 };

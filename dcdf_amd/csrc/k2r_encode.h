@@ -934,9 +934,20 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         return inval(br << h, bc << h);
     };
 
-    uint32_t off = 6;            // chunk header: encoding, fractional_bits, n_blocks (chunk.rs:236-238)
+    // Speculative halves (near-linear scaling when a GPU holds few chunks per CU): a chunk's instants may be encoded by two
+    // work items.  The first, [0, m), is an ordinary encode of those instants.  The second, [m, T), is a CONTINUATION: it
+    // assumes what holds for 31 instants in 32 on the benchmark's data -- that no block boundary falls into [1, m), so that
+    // instant 0 is still the open block's snapshot and the block holds m instants -- and starts from there: it first rebuilds
+    // instant 0's extremes and compact copy ("priming", one analysis-only pass), then runs chunk.rs:55-74 from instant m on,
+    // writing its Logs and Blocks from byte 0 of its own slot.  stitch_halves() checks the assumption against the first
+    // half's result (exactly one snapshot) and splices the bytes; otherwise the chunk is re-encoded whole.
+    const uint32_t i_begin = ta.inst_begin, i_end = ta.inst_end != 0 ? ta.inst_end : ta.instants;
+    const bool cont = i_begin > 0;
+    constexpr uint32_t NO_HDR = 0xffffffffu;  // the open block's count byte lives in the first half's bytes
+    uint32_t carry = 0;
+    uint32_t off = cont ? 0u : 6u;            // chunk header: encoding, fractional_bits, n_blocks (chunk.rs:236-238)
     uint32_t n_blocks = 0;
-    uint32_t blk_hdr = 6;        // where the open block's n_instants byte goes (block.rs:89)
+    uint32_t blk_hdr = cont ? NO_HDR : 6u;    // where the open block's n_instants byte goes (block.rs:89)
     uint32_t blk_count = 0;      // instants in the open block
     uint32_t s_idx = 0;          // instant of the open block's snapshot (chunk.rs:52)
     // The open block's snapshot instant is compared with every later instant of the block, so it is read 30 times as
@@ -955,18 +966,36 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             sh.stQ = 0;
             for (int i = 0; i < 6; i++) sh.fault[i] = 0;
             for (int i = 0; i < NPROF; i++) sh.prof[i] = 0;
-            if (cap >= 6) {
+            if (cap >= 6 && !cont) {
                 out[0] = (uint8_t)ta.dtype;
                 out[1] = (uint8_t)ta.fbits;
             }
         }
     });
-    if (cap < 7) status = ST_OUT_CAPACITY;
+    if (cap < 7 && !cont) status = ST_OUT_CAPACITY;
 #ifdef K2R_PROFILE
     if (!EX::kSim) ex.par([&](int tid, EncRegs&) { if (tid == 0) sh.prof_last = clock64(); });
 #endif
 
-    for (uint32_t inst = 0; inst < ta.instants && status == ST_OK; inst++) {
+    // the compact copy of instant `from` (the open block's snapshot) for the logs that follow
+    auto compact_pass = [&](uint32_t from) {
+        ex.par_nosync([&](int tid, EncRegs&) {
+            uint32_t r0, c0;
+            blk_origin(tid, r0, c0);
+            int32_t lerr = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                int32_t t16[16];
+                load_sub16<PADDED, VEC>(ta, from, r0, c0, j, t16, lerr);
+                store_compact<C>(scmp, tid, j, s_base, t16);
+            }
+        });
+        ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
+    };
+
+    for (uint32_t it = cont ? i_begin - 1 : 0u; it < i_end && status == ST_OK; it++) {
+        const bool priming = cont && it + 1 == i_begin;  // a continuation's first pass: instant 0, analysis only
+        const uint32_t inst = priming ? 0u : it;
         const bool have_s = inst > 0;
         // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
         // Nothing but four per-height-2 summaries survives this phase in registers: cells are re-read on
@@ -1165,6 +1194,15 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             });
         }
 
+        if (priming) {  // instant 0 as the open block's snapshot: its extremes decide the compact copy (as in the as_snapshot branch)
+            const int32_t rmin = ex.uni(sh.tmin[C::top_off(H)]), rmax = ex.uni(sh.tmax[C::top_off(H)]);
+            s_cmp = (int64_t)rmax - (int64_t)rmin <= 65535;
+            s_base = rmin;
+            s_idx = 0;
+            blk_count = i_begin;
+            if (s_cmp) compact_pass(0);
+            continue;
+        }
         ex.stamp(1);  // phase 2: top of the tree
         // node predicates on the top arrays (index = top_off(h) + j)
         auto PS = [&](int h, uint32_t j) -> bool {
@@ -1525,9 +1563,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         bool do_patch = false;
         if (as_snapshot) {
             if (have_s) {  // close the open block (chunk.rs:63-70)
-                do_patch = true;
-                hdr_patch_off = blk_hdr;
-                hdr_patch_val = blk_count;
+                if (blk_hdr == NO_HDR) carry = blk_count;  // the inherited block: stitch_halves() patches its count byte
+                else {
+                    do_patch = true;
+                    hdr_patch_off = blk_hdr;
+                    hdr_patch_val = blk_count;
+                }
                 n_blocks++;
             }
             blk_hdr = off;
@@ -1815,20 +1856,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
             ex.stamp(9);
         } else {
-            if (as_snapshot && s_cmp) {  // leave the compact copy of this snapshot instant for the logs that follow
-                ex.par_nosync([&](int tid, EncRegs&) {
-                    uint32_t r0, c0;
-                    blk_origin(tid, r0, c0);
-                    int32_t lerr = 0;
-#pragma unroll 1
-                    for (int j = 0; j < 4; j++) {
-                        int32_t t16[16];
-                        load_sub16<PADDED, VEC>(ta, inst, r0, c0, j, t16, lerr);
-                        store_compact<C>(scmp, tid, j, s_base, t16);
-                    }
-                });
-                ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
-            }
+            if (as_snapshot && s_cmp) compact_pass(inst);  // leave the compact copy of this snapshot instant for the logs that follow
             passA(EmTag<EM_LIST>{});
             ex.barrier();  // pass B consumes the work list pass A built
             ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
@@ -1963,9 +1991,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     ex.par([&](int tid, EncRegs&) {
         if (tid == 0) {
             if (status == ST_OK) {
-                out[blk_hdr] = (uint8_t)blk_count;
-                store_be32(out + 2, n_blocks + 1);
+                if (blk_hdr == NO_HDR) carry = blk_count;  // the inherited block never closed
+                else out[blk_hdr] = (uint8_t)blk_count;
+                if (!cont) store_be32(out + 2, n_blocks + 1);
             }
+            res->carry_count = carry;
             const bool faulted = sh.fault[0] != 0;
             res->status = faulted ? (int32_t)ST_INTERNAL : status;
             res->snapshots = n_snap;

@@ -33,6 +33,9 @@ static void run_l(const TileArgs& ta, TileResult* res, bool padded, int vec) {
     else run<LOG2S, false, 0>(ta, res);
 }
 
+static uint32_t g_split_at = 0;  // > 0: encode as two speculative halves [0, m) + [m, T) and splice (mirrors k_stitch)
+extern "C" void sim_set_split(uint32_t m) { g_split_at = m; }
+
 static uint32_t g_last_stash_logs = 0;
 extern "C" uint32_t sim_last_stash_logs() { return g_last_stash_logs; }
 
@@ -58,13 +61,46 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
                         ((uint64_t)(rows - 1) * (uint64_t)sr + cols) * esz < (1ull << 31);
     const int vec = !rows16 ? 0 : (dtype == ENC_I32 ? 1 : (dtype == ENC_F32 ? 2 : (dtype == ENC_I64 ? 3 : 4)));
     TileResult res{};
-    switch (lg) {
-        case 3: run_l<3>(ta, &res, padded, vec); break;
-        case 4: run_l<4>(ta, &res, padded, vec); break;
-        case 5: run_l<5>(ta, &res, padded, vec); break;
-        case 6: run_l<6>(ta, &res, padded, vec); break;
-        case 7: run_l<7>(ta, &res, padded, vec); break;
-        case 8: run_l<8>(ta, &res, padded, vec); break;
+    auto run_lg = [&](const TileArgs& a, TileResult* r) {
+        switch (lg) {
+            case 3: run_l<3>(a, r, padded, vec); break;
+            case 4: run_l<4>(a, r, padded, vec); break;
+            case 5: run_l<5>(a, r, padded, vec); break;
+            case 6: run_l<6>(a, r, padded, vec); break;
+            case 7: run_l<7>(a, r, padded, vec); break;
+            case 8: run_l<8>(a, r, padded, vec); break;
+        }
+    };
+    if (g_split_at > 0 && g_split_at < instants) {
+        // the splice of k2r_capi_encode.hip's k_stitch, on the host
+        TileArgs a = ta, b = ta;
+        a.inst_end = g_split_at;
+        b.inst_begin = g_split_at;
+        b.inst_end = instants;
+        std::vector<uint8_t> outb(cap);
+        b.out = outb.data();
+        TileResult rb{};
+        run_lg(a, &res);
+        run_lg(b, &rb);
+        int32_t st = ST_OK;
+        if (res.status != ST_OK) st = res.status;
+        else if (res.snapshots != 1) st = ST_RESPLIT;
+        else if (rb.status != ST_OK) st = rb.status;
+        else if (res.len + rb.len > cap) st = ST_OUT_CAPACITY;
+        if (st == ST_OK) {
+            std::memcpy(out + res.len, outb.data(), rb.len);
+            out[6] = (uint8_t)rb.carry_count;
+            store_be32(out + 2, 1u + rb.snapshots);
+            res.len += rb.len;
+            res.snapshots += rb.snapshots;
+            res.logs += rb.logs;
+            res.stash_logs += rb.stash_logs;
+        } else {
+            res.status = st;
+            res.len = 0;
+        }
+    } else {
+        run_lg(ta, &res);
     }
     g_last_stash_logs = res.stash_logs;
     *status = res.status; *snapshots = res.snapshots; *logs = res.logs; *len = res.len;

@@ -255,3 +255,26 @@ def test_object_sha256_on_device(dc):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _SHA_SCRIPT % root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sha256 ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_speculative_halves_splice(dc, monkeypatch):
+    """K2R_SPLIT=all: every tile is encoded as two work items ([0, T/2) and a continuation that assumes the first block is
+    still open) and spliced on the device by k_stitch.  Bytes, counters and per-instant (min, max) must equal the sequential
+    encode's -- including tiles whose first half closes a block (the assumption fails: re-encoded whole), padded tiles, other
+    element types and chunks too short to split."""
+    from dcdf_amd import synth
+    monkeypatch.setenv("K2R_SPLIT", "all")
+    arrays = [synth.cells(0xDCDF0003, 32 * s, 32 * s + 32, 256 * i, 256 * i + 256, 0, 256, np.int32) for s, i in [(0, 0), (1, 3), (2, 5)]]
+    arrays.append(synth.cells(0xDCDF0003, 352, 365, 0, 256, 256, 512, np.int32))          # the 13-instant last segment
+    arrays.append(synth.cells(0xDCDF0002, 0, 9, 0, 200, 0, 256, np.int32))                 # padded
+    arrays.append(synth.cells(0xDCDF0002, 0, 8, 0, 128, 0, 128, np.int64))
+    noisy = arrays[0].copy()
+    noisy[5] = np.random.default_rng(5).integers(0, 1 << 20, size=noisy[5].shape)         # a snapshot inside the first half
+    arrays.append(noisy)
+    late = arrays[1].copy()
+    late[20:] = np.random.default_rng(6).integers(0, 1 << 20, size=late[20:].shape)       # block boundaries in the second half only
+    arrays.append(late)
+    arrays.append(arrays[2][:3].copy())                                                    # 3 instants: not split
+    assert_same(dc, arrays)
+    f = (arrays[5][:, :64, :64] // 2 / 8.0).astype(np.float32)
+    assert_same(dc, [f], fractional_bits=3)

@@ -263,3 +263,44 @@ def test_property_random_tiles(instants, rows, cols, seed, kind, dtype):
         assert S.encode(a)[0] == -8
         return
     check(a)
+
+
+def test_speculative_halves():
+    """A chunk encoded as two work items (k2r_encode.h "speculative halves", spliced as k_stitch does): byte-identical to the
+    sequential encode whenever the first half holds a single block; reported as -102 (re-encode whole) when a block boundary
+    falls into the first half; errors of either half surface."""
+    L = S.lib()
+    try:
+        rng = np.random.default_rng(9)                                       # one block: every log beats its snapshot
+        a = (rng.integers(0, 4000, size=(64, 64))[None] + (rng.random((9, 64, 64)) < 0.03) * rng.integers(-300, 300, size=(9, 64, 64))).astype(np.int32)
+        a[5] = a[4]
+        assert S.encode(a)[2] == 1
+        ref = check(a)[0]
+        for m in (1, 2, 4, 5, 8):
+            L.sim_set_split(m)
+            assert check(a)[0] == ref
+        L.sim_set_split(4)
+        check(a[:, :50, :37])                                                # padded tile
+        check(a.astype(np.int64) * 2 + 1)
+        check((a / 8.0).astype(np.float32), fractional_bits=3)
+        b = a.copy()                                                         # a block boundary INSIDE the second half
+        b[6:] = np.random.default_rng(6).integers(0, 1 << 20, size=b[6:].shape)
+        st, data, ns, nl = S.encode(b)
+        assert st == 0 and ns >= 2
+        ref_b = O.chunk_build(b)
+        assert data == ref_b
+        for m in (2, 4, 6):
+            L.sim_set_split(m)
+            assert S.encode(b)[1] == ref_b
+        L.sim_set_split(7)                                                   # boundary at instant 6 < 7: the assumption fails
+        assert S.encode(b)[0] == -102
+        c = array_n(16, T=12).astype(np.int64)                               # the reference fixture: blocks of 3 (a8 repeats)
+        _, _, ns, _ = S.encode(c)
+        L.sim_set_split(6)
+        assert S.encode(c)[0] == (-102 if ns > 1 else 0)
+        d = a.astype(np.int64)                                               # an out-of-contract value in the second half only
+        d[7, 3, 3] = 2 ** 31
+        L.sim_set_split(4)
+        assert S.encode(d)[0] == -8
+    finally:
+        L.sim_set_split(0)
