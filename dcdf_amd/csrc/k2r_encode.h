@@ -550,6 +550,14 @@ struct EncPool {
     static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
     static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
     static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? 4900 : 0);  // sidelen 256: LDS filled to 160 KB
+    // The stash's two record kinds have fixed shares of the pool (I records grow up from word 0, Q records down from POOLW);
+    // records beyond a share go to a per-workgroup overflow area in global scratch (L2), so an instant with unusually many
+    // records -- a snapshot with forced-constant 64x64 blocks makes every quad under them internal -- still takes the stash
+    // path (the re-reading fallback is 2.2 x slower per instant, and the 3 % of chunks that hit it set the tail of a launch).
+    static constexpr int CAPI_REC = (POOLW * 53 / 100) / 5;
+    static constexpr int CAPQ_REC = (POOLW - 5 * CAPI_REC) / 3;
+    static constexpr int OVI_WORDS = 5 * 4 * C::NBLK;    // every height-2 node internal
+    static constexpr int OVQ_WORDS = 3 * 16 * C::NBLK;   // every quad internal
 };
 
 template <class C>
@@ -791,6 +799,42 @@ K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
     __builtin_memcpy(p, &v, 4);
 #endif
 }
+// stash records that overflowed to global scratch: N consecutive 32-bit words (4-byte aligned)
+K2R_HD void gstore_words3(uint32_t* p, uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u3 __attribute__((ext_vector_type(3), aligned(4)));
+    *(__attribute__((address_space(1))) u3*)p = u3{a, b, c};
+#else
+    p[0] = a; p[1] = b; p[2] = c;
+#endif
+}
+K2R_HD void gstore_words5(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(4)));
+    *(__attribute__((address_space(1))) u4*)p = u4{a, b, c, d};
+    *(__attribute__((address_space(1))) uint32_t*)(p + 4) = e;
+#else
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d; p[4] = e;
+#endif
+}
+template <int N>
+K2R_HD void gload_words(const uint32_t* p, uint32_t (&w)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(N == 3 || N == 5, "record sizes");
+    if (N == 3) {
+        typedef uint32_t u3 __attribute__((ext_vector_type(3), aligned(4)));
+        const u3 v = *(__attribute__((address_space(1))) const u3*)p;
+        w[0] = v.x; w[1] = v.y; w[2] = v.z;
+    } else {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(4)));
+        const u4 v = *(__attribute__((address_space(1))) const u4*)p;
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        w[N - 1] = *(__attribute__((address_space(1))) const uint32_t*)(p + 4);
+    }
+#else
+    for (int i = 0; i < N; i++) w[i] = p[i];
+#endif
+}
 // WHICH = 0: Lmax Dac (sh.bmV0, sh.nlistV); 1: Lmin Dac (sh.bmM[0], sh.nlistM)
 template <int WHICH, int MODE = EM_LIST, class EX>
 K2R_HD void emit_val(EX& ex, const DacSink& d, uint32_t pos, uint32_t zz, int tid, uint32_t lpos = 0) {
@@ -900,14 +944,18 @@ K2R_HD void dac_finish(EX& ex, const DacLayout& L, uint8_t* inst_out, uint32_t* 
 // int64 (3) / float64 (4) input with unit column stride and 16-byte aligned rows (=> vector loads), implies !PADDED.
 // ======================================================================================================
 template <class C, bool PADDED, int VEC, class EX>
-K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM, uint32_t* scmp) {
+K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* listV, uint64_t* listM, uint32_t* scmp, uint32_t* ovf) {
     constexpr int H = C::H;
     constexpr int NT = C::NT;
     auto& sh = ex.sh;
     using SH = EncShared<C>;
     static_assert(!(PADDED && VEC != 0), "vector loads need an unpadded tile");
     // words of the LDS pool the stash may use (ta.stash_words: 0 = all of it; tests shrink it to force the fallback)
-    const uint32_t stash_cap = (ta.stash_words != 0 && ta.stash_words < (uint32_t)SH::POOLW) ? ta.stash_words : (uint32_t)SH::POOLW;
+    // ta.stash_words (tests, A/B runs): an instant whose records need more words than this takes the re-reading fallback
+    // passes instead of the stash; 0 = never (what does not fit the LDS pool overflows to global scratch: EncPool)
+    const uint32_t stash_cap = ta.stash_words != 0 ? ta.stash_words : 0xffffffffu;
+    uint32_t* const ovI = ovf;                    // I records number CAPI_REC and up
+    uint32_t* const ovQ = ovf + SH::OVI_WORDS;    // Q records number CAPQ_REC and up
 
     uint8_t* const out = ta.out;
     const uint64_t cap = ta.out_cap;
@@ -1088,11 +1136,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         }
                         if (P1L) {  // Q record: owner, ordinal among the owner's internal quads, the four cell diffs
                             const uint32_t m = ex.lds_add(&sh.stQ, 1u);
-                            if (3u * (m + 1u) <= stash_cap) {
+                            const uint32_t q0 = (uint32_t)tid | (lI1 << 10) | ((lc & 127u) << 14);
+                            const uint32_t q1 = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16);
+                            const uint32_t q2 = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
+                            if (m < (uint32_t)SH::CAPQ_REC) {
                                 uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
-                                q[0] = (uint32_t)tid | (lI1 << 10) | ((lc & 127u) << 14);
-                                q[1] = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16);
-                                q[2] = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
+                                q[0] = q0;
+                                q[1] = q1;
+                                q[2] = q2;
+                            } else {  // (separate code paths on purpose: an LDS-or-global pointer would turn both into FLAT stores)
+                                gstore_words3(ovQ + 3u * (m - (uint32_t)SH::CAPQ_REC), q0, q1, q2);
                             }
                         }
                         lI1 += P1L ? 1u : 0u;
@@ -1109,14 +1162,17 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const bool P2L = !inv2 && mn2 != mx2 && !eq2;
                     if (P2L) {  // I record: owner, ordinals, T / eqB runs and the Lmax|Lmin pairs of the four quads
                         const uint32_t k = ex.lds_add(&sh.stI, 1u);
-                        if (5u * (k + 1u) <= stash_cap) {
+                        const uint32_t p0 = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (tb1 << 16) | (erun << 20) | (((lc >> 7) & 31u) << 24) |
+                                            (((lc0 >> 15) & 31u) << 28);
+                        if (k < (uint32_t)SH::CAPI_REC) {
                             uint32_t* p = sh.pool + 5u * k;
-                            p[0] = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (tb1 << 16) | (erun << 20) | (((lc >> 7) & 31u) << 24) |
-                                   (((lc0 >> 15) & 31u) << 28);
+                            p[0] = p0;
                             p[1] = recw[0];
                             p[2] = recw[1];
                             p[3] = recw[2];
                             p[4] = recw[3];
+                        } else {
+                            gstore_words5(ovI + 5u * (k - (uint32_t)SH::CAPI_REC), p0, recw[0], recw[1], recw[2], recw[3]);
                         }
                     }
                     lI2 += P2L ? 1u : 0u;
@@ -1624,6 +1680,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
         });
 
+        // records that overflowed to global scratch are read by other threads: their stores must have landed
+        if (use_stash && (stI > (uint32_t)SH::CAPI_REC || stQ > (uint32_t)SH::CAPQ_REC)) ex.barrier_global();
         ex.stamp(4);  // sizes, heuristic, clears, header
         const uint32_t nlevV = ex.uni(DV.nlev), nlevM = ex.uni(DM.nlev);
         const DacSink sinkV{io + ex.uni(DV.by_off[0]), sh.bmV0, listV, &sh.nlistV, ex.uni(DV.n[0]), ex.uni(DV.n[1]), inst, kGuardVPos,
@@ -1778,7 +1836,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 const uint32_t offV1 = TT.offV[1], offZ1 = TT.offZ[1], offI1 = TT.offI[1], lt = TT.LT, ne = TT.LT - TT.M0;
                 const uint32_t lv1 = sh.pl.lngV[1], lm1 = sh.pl.lngM[1];
                 for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
-                    const uint32_t* rec = sh.pool + 5u * k;
+                    uint32_t rec[5];
+                    if (k < (uint32_t)SH::CAPI_REC) {
+#pragma unroll
+                        for (int i = 0; i < 5; i++) rec[i] = sh.pool[5u * k + i];
+                    } else {
+                        gload_words<5>(ovI + 5u * (k - (uint32_t)SH::CAPI_REC), rec);
+                    }
                     const uint32_t hdr = rec[0];
                     const uint32_t own = hdr & 1023u;
                     const uint32_t pf = sh.pfx[0][own], pl = sh.pfx[2][own];
@@ -1812,7 +1876,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             ex.par([&](int tid, EncRegs&) {
                 const uint32_t offV0 = TT.offV[0], lv0 = sh.pl.lngV[0];
                 for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
-                    const uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
+                    uint32_t q[3];
+                    if (m < (uint32_t)SH::CAPQ_REC) {
+#pragma unroll
+                        for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::POOLW - 3u * (m + 1u) + i];
+                    } else {
+                        gload_words<3>(ovQ + 3u * (m - (uint32_t)SH::CAPQ_REC), q);
+                    }
                     const uint32_t hdr = q[0], a = q[1], b = q[2];
                     const uint32_t own = hdr & 1023u;
                     const uint32_t pos = (sh.pfx[0][own] & 0xffffu) + ((hdr >> 10) & 15u);  // rank among internal quads

@@ -19,10 +19,11 @@ k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, c
     using C = EncCfg<LOG2S>;
     __shared__ EncShared<C> sh;
     GpuExec<EncShared<C>, EncRegs, C::NT> ex(sh);
-    // per-workgroup global scratch: the two overflow lists and the compact snapshot copy (16 u64 words per thread)
-    uint64_t* listV = lists + (size_t)blockIdx.x * (C::MAXV + C::MAXT + 2 + 16 * C::NT);
+    // per-workgroup global scratch: the two overflow lists, the compact snapshot copy (16 u64 words per thread), the stash overflow
+    uint64_t* listV = lists + (size_t)blockIdx.x * (C::MAXV + C::MAXT + 2 + 16 * C::NT + (5 * 4 + 3 * 16) * C::NBLK / 2);
     uint64_t* listM = listV + (C::MAXV + 1);
     uint32_t* scmp = (uint32_t*)(listM + (C::MAXT + 1));
+    uint32_t* ovf = scmp + 32 * C::NT;  // stash records beyond the LDS pool's shares (EncPool::OVI_WORDS + OVQ_WORDS words)
     for (;;) {
         if (threadIdx.x == 0) sh.work = atomicAdd(queue, 1u);
         __syncthreads();
@@ -32,7 +33,7 @@ k_encode(const TileArgs* __restrict__ tiles, TileResult* __restrict__ results, c
         __syncthreads();
         if (w >= n) break;  // uniform: every wave of the workgroup leaves together
         const uint32_t ti = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[w]);
-        encode_chunk<C, PADDED, VEC>(ex, tiles[ti], &results[ti], listV, listM, scmp);
+        encode_chunk<C, PADDED, VEC>(ex, tiles[ti], &results[ti], listV, listM, scmp, ovf);
     }
 }
 

@@ -31,7 +31,9 @@ int encode_blocks_per_cu(const EncClass& cls) {
 size_t encode_list_words(const EncClass& cls) {  // u64 words of global scratch per workgroup (k2r_encode_inst.hip)
     const int H = cls.log2s;
     const size_t maxv = ((1u << (2 * (H + 1))) - 1) / 3, maxt = ((1u << (2 * H)) - 1) / 3;
-    return maxv + maxt + 2 + 16 * ((size_t)1 << (2 * (H - 3)));  // + the compact snapshot copy (128 B per thread)
+    const size_t nblk = (size_t)1 << (2 * (H - 3));
+    // + the compact snapshot copy (128 B per thread) + the stash overflow area (EncPool::OVI_WORDS + OVQ_WORDS 32-bit words)
+    return maxv + maxt + 2 + 16 * nblk + (5 * 4 + 3 * 16) * nblk / 2;
 }
 int encode_threads(const EncClass& cls) { return 1 << (2 * (cls.log2s - 3)); }
 

@@ -20,7 +20,8 @@ static void run(const TileArgs& ta, TileResult* res) {
     std::memset((void*)ex.regs.data(), 0x5A, ex.regs.size() * sizeof(EncRegs));  // registers start as garbage on a GPU
     std::vector<uint64_t> listV(C::MAXV + 1), listM(C::MAXT + 1);
     std::vector<uint32_t> scmp(32 * C::NT, 0xA5A5A5A5u);
-    encode_chunk<C, PADDED, VEC>(ex, ta, res, listV.data(), listM.data(), scmp.data());
+    std::vector<uint32_t> ovf((size_t)(5 * 4 + 3 * 16) * C::NBLK, 0xA5A5A5A5u);
+    encode_chunk<C, PADDED, VEC>(ex, ta, res, listV.data(), listM.data(), scmp.data(), ovf.data());
 }
 
 template <int LOG2S>

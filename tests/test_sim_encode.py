@@ -304,3 +304,15 @@ def test_speculative_halves():
         assert S.encode(d)[0] == -8
     finally:
         L.sim_set_split(0)
+
+
+def test_stash_overflow_goes_to_global_scratch():
+    """A snapshot instant with constant 64x64 blocks makes every quad under them internal in the logs that follow: more stash
+    records than the LDS pool's shares hold (EncPool::CAPI_REC / CAPQ_REC).  The excess goes to global scratch and the logs
+    are still emitted from the stash (no re-reading fallback), byte-identical."""
+    a = synth.cells(0xDCDF0002, 0, 3, 0, 256, 0, 256, np.int32)
+    a[0, :128, :128] = 77       # 4 of the 16 blocks of the snapshot instant constant: 4096 internal quads there alone
+    a[2, 64:128, 64:192] = -5   # and a constant stretch in a later instant
+    data, _ = check(a)
+    _, _, ns, nl = S.encode(a)
+    assert ns == 1 and nl == 2 and _stash_logs() == 2
