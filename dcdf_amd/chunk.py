@@ -113,10 +113,37 @@ class Chunk:
         if not lazy:
             self._open()
 
+    @classmethod
+    def open_batch_device(cls, ptrs, lens, fetch=None):
+        """dcdf_chunk_open_batch(DCDF_MEM_DEVICE): ptrs / lens = ctypes arrays of device pointers and byte counts of encoded
+        chunks already in HBM.  `fetch(j)` (optional) returns chunk j's bytes for write_to() -- they are only copied to the
+        host when asked for."""
+        n = len(ptrs)
+        hs = (C.c_void_p * n)()
+        st = (C.c_int32 * n)()
+        L.check(L.lib().dcdf_chunk_open_batch(ptrs, lens, C.c_size_t(n), L.MEM_DEVICE, hs, st), "chunk_open_batch")
+        out = []
+        for j in range(n):
+            if st[j] != 0:
+                for o in out:
+                    o.close()
+                raise L.DcdfError(st[j], "chunk_open_batch: chunk %d" % j)
+            c = cls.__new__(cls)
+            c._bytes = None
+            c._fetch = (lambda j=j: fetch(j)) if fetch else None
+            c._handle = C.c_void_p(hs[j])
+            c._read_info()
+            out.append(c)
+        return out
+
     def _open(self):
         h = C.c_void_p()
         L.check(L.lib().dcdf_chunk_open(self._bytes, C.c_size_t(len(self._bytes)), C.byref(h)), "Chunk::read_from")
         self._handle = h
+        self._read_info()
+
+    def _read_info(self):
+        h = self._handle
         shp = (C.c_uint32 * 3)()
         enc, fb, nb = C.c_int32(), C.c_uint32(), C.c_uint32()
         L.check(L.lib().dcdf_chunk_info(h, shp, C.byref(enc), C.byref(fb), C.byref(nb)))
@@ -163,10 +190,14 @@ class Chunk:
         return cls(data)
 
     def write_to(self):  # chunk.rs:235
+        if self._bytes is None:  # opened from device memory: the bytes come to the host only now
+            if getattr(self, "_fetch", None) is None:
+                raise ValueError("this chunk was opened from device memory without a way to fetch its bytes")
+            self._bytes = self._fetch()
         return self._bytes
 
     def size(self):  # chunk.rs:272
-        return len(self._bytes)
+        return len(self.write_to())
 
     def shape(self):  # chunk.rs:119
         self._h
@@ -220,6 +251,61 @@ class Chunk:
                 continue
             L.check(rc, "Chunk::iter_search")
             return out[:n.value]
+
+
+def _handles(chunks):
+    return (C.c_void_p * len(chunks))(*[c._h for c in chunks])
+
+
+def get_batch(chunks, points, out_device_ptr=None):
+    """Chunk::get for many (chunk, (instant, row, col)) pairs in one launch (dcdf_query_get_batch; what Superchunk::get,
+    superchunk.rs:313-352, routes).  Returns int64[n] stored values, or writes them to device memory at out_device_ptr."""
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint32).reshape(-1, 3))
+    n = len(pts)
+    out = None if out_device_ptr else np.zeros(n, dtype=np.int64)
+    L.check(L.lib().dcdf_query_get_batch(_handles(chunks), C.c_void_p(pts.ctypes.data), C.c_size_t(n),
+                                         C.c_void_p(out_device_ptr or out.ctypes.data), L.MEM_DEVICE if out_device_ptr else L.MEM_HOST,
+                                         None), "get_batch")
+    return out
+
+
+def fill_cell_batch(chunks, cells):
+    """Chunk::fill_cell for many (chunk, (start, end, row, col)) in one launch (superchunk.rs:356-400).  Returns the list of
+    int64 series."""
+    cl = np.ascontiguousarray(np.asarray(cells, dtype=np.uint32).reshape(-1, 4))
+    n = len(cl)
+    ln = np.abs(cl[:, 1].astype(np.int64) - cl[:, 0].astype(np.int64)).astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        off[1:] = np.cumsum(ln)[:-1]
+    out = np.zeros(max(1, int(ln.sum())), dtype=np.int64)
+    L.check(L.lib().dcdf_query_fill_cell_batch(_handles(chunks), C.c_void_p(cl.ctypes.data), C.c_size_t(n), C.c_void_p(out.ctypes.data),
+                                               C.c_void_p(off.ctypes.data), L.MEM_HOST, None), "fill_cell_batch")
+    return [out[int(off[i]):int(off[i]) + int(ln[i])] for i in range(n)]
+
+
+def fill_window_batch(chunks, cubes, dtype=np.int64, out_device_ptr=None, out_offset=None):
+    """fill_window of many (chunk, Cube) pairs in one launch with a typed result (dcdf_query_fill_window_batch_typed).  Host
+    form: returns (flat ndarray of dtype, offsets uint64[n]) with window q at flat[offsets[q]:]; device form
+    (out_device_ptr): the kernel writes window q at element out_offset[q] of the caller's device array, returns kernel ms."""
+    dtype = np.dtype(dtype)
+    cub = (L.Cube * len(cubes))(*[c._c() for c in cubes])
+    vol = np.array([c.instants() * c.rows() * c.cols() for c in cubes], dtype=np.uint64)
+    ms = C.c_float()
+    if out_device_ptr is None:
+        off = np.zeros(len(cubes), dtype=np.uint64)
+        if len(cubes) > 1:
+            off[1:] = np.cumsum(vol)[:-1]
+        out = np.zeros(max(1, int(vol.sum())), dtype=dtype)
+        L.check(L.lib().dcdf_query_fill_window_batch_typed(_handles(chunks), cub, C.c_size_t(len(cubes)), C.c_void_p(out.ctypes.data),
+                                                           _ENC[dtype], L.MEM_HOST, C.c_void_p(off.ctypes.data), C.byref(ms)),
+                "fill_window_batch")
+        return out, off
+    off = np.ascontiguousarray(np.asarray(out_offset, dtype=np.uint64))
+    L.check(L.lib().dcdf_query_fill_window_batch_typed(_handles(chunks), cub, C.c_size_t(len(cubes)), C.c_void_p(out_device_ptr),
+                                                       _ENC[dtype], L.MEM_DEVICE, C.c_void_p(off.ctypes.data), C.byref(ms)),
+            "fill_window_batch")
+    return ms.value
 
 
 # py-dcdf flavoured helpers (SURVEY 8b "Python shape")

@@ -1001,5 +1001,5 @@ extern "C" const char* dcdf_device_name(void) {
     Runtime& rt = Runtime::get();
     return rt.ok ? rt.name.c_str() : nullptr;
 }
-extern "C" int dcdf_abi_version(void) { return 2; }
+extern "C" int dcdf_abi_version(void) { return 3; }
 extern "C" int dcdf_last_hip_error(void) { return k2r::last_hip_error(); }

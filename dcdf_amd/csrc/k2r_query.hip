@@ -22,6 +22,13 @@ struct dcdf_chunk {
     uint32_t fbits = 0;
     size_t len = 0;
     DevBuf d_bytes, d_descs;
+    // where the device-side views live: the chunk's own buffers (dcdf_chunk_open) or a slab shared by a batch
+    // (dcdf_chunk_open_batch); make_ref() reads only these
+    const uint8_t* p_bytes = nullptr;
+    const InstDesc* p_descs = nullptr;
+    const void* p_top = nullptr;
+    const void* p_top_mm = nullptr;
+    std::shared_ptr<void> store;  // keeps a batch's slab alive until its last chunk is closed
     // k = 2, sidelen 32..256: for every instant the walk's state at each node of side 16 (k_top_table, built at open): the wave
     // walks of fill_window / search start there instead of at the root (an item begins with
     // the entries of the squares it meets)
@@ -73,22 +80,22 @@ struct Cursor {
     const uint8_t* p;
     size_t n, pos = 0;
     bool ok = true;
-    bool need(size_t k) {
+    K2R_HD bool need(size_t k) {
         if (!ok || pos + k > n || pos + k < pos) ok = false;
         return ok;
     }
-    uint8_t u8() { return need(1) ? p[pos++] : 0; }
-    uint32_t u32() {
+    K2R_HD uint8_t u8() { return need(1) ? p[pos++] : 0; }
+    K2R_HD uint32_t u32() {
         if (!need(4)) return 0;
         uint32_t v = load_be32(p + pos);
         pos += 4;
         return v;
     }
-    void skip(size_t k) {
+    K2R_HD void skip(size_t k) {
         if (need(k)) pos += k;
     }
 };
-static void parse_bitmap(Cursor& c, BmDesc& d) {
+K2R_HD void parse_bitmap(Cursor& c, BmDesc& d) {
     d.len = c.u32();
     d.k = c.u32();
     if (d.k == 0) c.ok = false;
@@ -98,8 +105,8 @@ static void parse_bitmap(Cursor& c, BmDesc& d) {
     d.words_off = (uint32_t)c.pos;
     c.skip(4ull * ((d.len + 31) / 32));
 }
-static void parse_dac(Cursor& c, DacDesc& d) {
-    std::memset(&d, 0, sizeof(d));
+K2R_HD void parse_dac(Cursor& c, DacDesc& d) {
+    d = DacDesc{};
     d.nlev = c.u8();
     if (d.nlev > 8) c.ok = false;
     for (uint32_t l = 0; l < d.nlev && c.ok; l++) {
@@ -108,8 +115,8 @@ static void parse_dac(Cursor& c, DacDesc& d) {
         c.skip(d.bm[l].len);
     }
 }
-static void parse_inst(Cursor& c, InstDesc& d, bool is_log, uint32_t snap) {
-    std::memset(&d, 0, sizeof(d));
+K2R_HD void parse_inst(Cursor& c, InstDesc& d, bool is_log, uint32_t snap) {
+    d = InstDesc{};
     d.is_log = is_log ? 1u : 0u;
     d.snap = snap;
     d.k = c.u8();
@@ -789,12 +796,10 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
 }
 // The walk's state at every node of side 16, for every instant of one chunk (dcdf_chunk::d_top): one wave per instant walks
 // the top of the tree(s) breadth-first -- 1, 4, 16, ... nodes -- with the same expand4 as the query walks.
-__global__ void __launch_bounds__(64)
-k_top_table(ChunkRef C, TopEnt* __restrict__ table, TopMM* __restrict__ table_mm, uint32_t* __restrict__ overflow) {
-    __shared__ WaveQ2 q;
-    __shared__ int64_t qmt[WQ2_CAP], qms[WQ2_CAP];  // the frontier nodes' min_t, min_s (log.rs:360-361)
+__device__ __forceinline__ void top_table_inst(const ChunkRef& C, const uint32_t inst, TopEnt* __restrict__ table, TopMM* __restrict__ table_mm,
+                                               uint32_t* __restrict__ overflow, WaveQ2& q, int64_t* qmt, int64_t* qms) {
     const int lane = threadIdx.x;
-    const uint32_t inst = blockIdx.x, G = C.top_g;
+    const uint32_t G = C.top_g;
     const uint8_t* const b = C.bytes;
     const gbytes gb = (gbytes)C.bytes;
     const gdesc gD = (gdesc)C.descs + inst;
@@ -890,6 +895,77 @@ k_top_table(ChunkRef C, TopEnt* __restrict__ table, TopMM* __restrict__ table_mm
         hi = cs == 16 ? hi : hi + tot;
     }
 }
+__global__ void __launch_bounds__(64)
+k_top_table(ChunkRef C, TopEnt* __restrict__ table, TopMM* __restrict__ table_mm, uint32_t* __restrict__ overflow) {
+    __shared__ WaveQ2 q;
+    __shared__ int64_t qmt[WQ2_CAP], qms[WQ2_CAP];  // the frontier nodes' min_t, min_s (log.rs:360-361)
+    top_table_inst(C, blockIdx.x, table, table_mm, overflow, q, qmt, qms);
+}
+// the same for every instant of MANY chunks in one launch (dcdf_chunk_open_batch): workgroup = one (chunk, instant);
+// inst_chunk[global instant] = its chunk, first_inst[chunk] = the chunk's first global instant; each chunk's tables are where
+// its ChunkRef says; overflow[chunk] != 0 afterwards = a value beyond int32 (that chunk is then walked from the root)
+__global__ void __launch_bounds__(64)
+k_top_table_batch(const ChunkRef* __restrict__ refs, const uint32_t* __restrict__ inst_chunk, const uint32_t* __restrict__ first_inst,
+                  uint32_t* __restrict__ overflow) {
+    __shared__ WaveQ2 q;
+    __shared__ int64_t qmt[WQ2_CAP], qms[WQ2_CAP];
+    const uint32_t ci = inst_chunk[blockIdx.x];
+    const ChunkRef C = refs[ci];
+    if (C.top_g == 0) return;
+    top_table_inst(C, blockIdx.x - first_inst[ci], (TopEnt*)C.top, (TopMM*)C.top_mm, overflow + ci, q, qmt, qms);
+}
+
+// ---- opening chunks whose bytes are already in device memory: the parse of chunk.rs:247-266 by one thread per chunk ----
+struct OpenMeta {
+    uint32_t ok, encoding, fbits, n_blocks, n_inst, k, rows, cols, sidelen, narrow32;
+};
+// count != 0: only count the instants (descs may be null); else fill descs[first[i] ..] and the per-instant quirk flags
+__global__ void __launch_bounds__(64)
+k_parse_chunks(const uint8_t* __restrict__ slab, const uint64_t* __restrict__ offs, const uint64_t* __restrict__ lens, uint32_t n,
+               const uint32_t* __restrict__ first, InstDesc* __restrict__ descs, uint8_t* __restrict__ quirk, OpenMeta* __restrict__ meta,
+               int count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* const b = slab + offs[i];
+    Cursor cur{b, (size_t)lens[i]};
+    OpenMeta m{};
+    m.encoding = cur.u8();
+    m.fbits = cur.u8();
+    m.n_blocks = cur.u32();
+    bool ok = m.encoding == DCDF_I32 || m.encoding == DCDF_I64 || m.encoding == DCDF_F32 || m.encoding == DCDF_F64;
+    uint32_t ni = 0;
+    InstDesc* const D = count ? nullptr : descs + first[i];
+    bool narrow = true;
+    for (uint32_t blk = 0; blk < m.n_blocks && cur.ok && ok; blk++) {
+        const uint32_t n_inst = cur.u8();  // block.rs:100
+        if (n_inst == 0) ok = false;
+        const uint32_t snap = ni;
+        for (uint32_t j = 0; j < n_inst && cur.ok && ok; j++, ni++) {
+            InstDesc d;
+            parse_inst(cur, d, j > 0, snap);
+            if (!cur.ok) break;
+            if (ni == 0) {
+                m.k = d.k; m.rows = d.rows; m.cols = d.cols; m.sidelen = d.sidelen;
+            } else if (d.k != m.k || d.rows != m.rows || d.cols != m.cols || d.sidelen != m.sidelen) ok = false;
+            if (d.T.k != 4 || (d.is_log && d.E.k != 4) || d.rows == 0 || d.cols == 0 || d.sidelen < (d.rows > d.cols ? d.rows : d.cols)) ok = false;
+            if (!count && ok) {
+                D[ni] = d;
+                int64_t hi = dacd_get(b, d.mx, 0), lo = dacd_get(b, d.mn, 0);
+                if (d.is_log) {  // log roots are differences against the snapshot's (log.rs:133,148)
+                    hi += dacd_get(b, D[snap].mx, 0);
+                    lo += dacd_get(b, D[snap].mn, 0);
+                }
+                const int64_t lim = (int64_t)1 << 30;
+                if (hi < -lim || hi >= lim || lo < -lim || lo >= lim) narrow = false;
+                quirk[first[i] + ni] = (d.is_log && !bmd_get(b, d.T, 0) && !bmd_get(b, d.E, 0) && bmd_get(b, D[snap].T, 0)) ? 1 : 0;
+            }
+        }
+    }
+    m.ok = (ok && cur.ok && ni > 0 && cur.pos == lens[i]) ? 1u : 0u;
+    m.n_inst = ni;
+    m.narrow32 = narrow ? 1u : 0u;
+    meta[i] = m;
+}
 // counts of the (query, instant) items the wave walk marked: one thread each over the bitmaps of the item's pieces
 __global__ void __launch_bounds__(64)
 k_search_count(const uint32_t* __restrict__ wbits, const SearchItem* __restrict__ items, const WinQuery* __restrict__ qs, uint32_t n,
@@ -920,6 +996,36 @@ k_get(const ChunkRef* __restrict__ chunks, const PointQuery* __restrict__ qs, ui
     const PointQuery Q = qs[q];
     const ChunkRef C = chunks[Q.chunk];
     out[q] = inst_get(C.bytes, C.descs, Q.instant, Q.row, Q.col);
+}
+
+// the same with explicit output positions (fill_cell batches: query q's series goes to out + out_offset[q])
+__global__ void __launch_bounds__(256)
+k_get_at(const ChunkRef* __restrict__ chunks, const PointQuery* __restrict__ qs, uint32_t nq, int64_t* __restrict__ out,
+         const uint64_t* __restrict__ at) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const PointQuery Q = qs[q];
+    const ChunkRef C = chunks[Q.chunk];
+    out[at[q]] = inst_get(C.bytes, C.descs, Q.instant, Q.row, Q.col);
+}
+// encoded chunks, wherever they lie in device memory, into one slab (16-byte aligned starts)
+struct SlabItem {
+    const uint8_t* src;
+    uint64_t len, dst_off;
+};
+__global__ void __launch_bounds__(256) k_slab_pack(const SlabItem* __restrict__ items, uint32_t n, uint8_t* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const SlabItem it = items[i];
+        if (((uintptr_t)it.src & 15u) == 0) {
+            const uint4* s4 = (const uint4*)it.src;
+            uint4* d4 = (uint4*)(dst + it.dst_off);
+            const uint64_t nv = it.len / 16;
+            for (uint64_t v = threadIdx.x; v < nv; v += blockDim.x) d4[v] = s4[v];
+            for (uint64_t b = 16 * nv + threadIdx.x; b < it.len; b += blockDim.x) dst[it.dst_off + b] = it.src[b];
+        } else {
+            for (uint64_t b = threadIdx.x; b < it.len; b += blockDim.x) dst[it.dst_off + b] = it.src[b];
+        }
+    }
 }
 
 // search pass 1: one thread per (query, instant) item runs the reference's pruned DFS and marks matches
@@ -1088,10 +1194,171 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
         K2R_HIP(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
         if (!ovf) c->top_g = g;
     }
+    c->p_bytes = c->d_bytes.as<uint8_t>();
+    c->p_descs = c->d_descs.as<InstDesc>();
+    c->p_top = c->d_top.p;
+    c->p_top_mm = c->d_top_mm.p;
     *h = c.release();
     return DCDF_OK;
 }
 extern "C" void dcdf_chunk_close(dcdf_chunk* h) { delete h; }
+
+namespace {
+struct BatchSlab {  // what the chunks of one dcdf_chunk_open_batch share
+    DevBuf bytes, descs, top, top_mm, refs;
+};
+}  // namespace
+
+// Many chunks at once.  mem = DCDF_MEM_HOST: dcdf_chunk_open one by one (full structural validation).  mem = DCDF_MEM_DEVICE:
+// the bytes are where an encoder session left them (dcdf_encoder_result's device pointers) -- they are packed into one slab,
+// parsed ON the device (k_parse_chunks, one thread per chunk: bounds-checked walk of the same layout, no host copy of the
+// bytes), and the side-16 tables of all their instants are built by ONE launch (k_top_table_batch, a wave per instant).
+// Device input is trusted to be the output of this library's encoders: the popcount cross-checks dcdf_chunk_open makes on
+// untrusted streams are not repeated.  status (may be NULL) receives one code per chunk; out[i] is NULL where it is not 0.
+extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t* lens, size_t n, int mem, dcdf_chunk** out,
+                                     int32_t* status) {
+    if (!bytes || !lens || !out || n == 0 || n > 0x7fffffffu || (mem != DCDF_MEM_HOST && mem != DCDF_MEM_DEVICE)) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    for (size_t i = 0; i < n; i++) out[i] = nullptr;
+    if (mem == DCDF_MEM_HOST) {
+        int first_err = DCDF_OK;
+        for (size_t i = 0; i < n; i++) {
+            const int rc = dcdf_chunk_open(bytes[i], (size_t)lens[i], &out[i]);
+            if (status) status[i] = rc;
+            if (rc != DCDF_OK && first_err == DCDF_OK) first_err = rc;
+        }
+        return status ? DCDF_OK : first_err;
+    }
+    auto slab = std::make_shared<BatchSlab>();
+    std::vector<SlabItem> items(n);
+    std::vector<uint64_t> offs(n);
+    uint64_t tot = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!bytes[i] || lens[i] < 6 || lens[i] > 0xfffffff0ull) return DCDF_ERR_BAD_ARG;
+        offs[i] = tot;
+        items[i] = SlabItem{bytes[i], lens[i], tot};
+        tot += (lens[i] + 64 + 15) & ~15ull;  // (slack: the wave decoder reads whole 16-byte blocks at a stream's tail)
+    }
+    DevBuf d_items, d_offs, d_lens, d_first, d_meta, d_quirk, d_ic, d_ovf;
+    K2R_HIP(slab->bytes.alloc(tot));
+    K2R_HIP(d_items.alloc(n * sizeof(SlabItem)));
+    K2R_HIP(hipMemcpy(d_items.p, items.data(), n * sizeof(SlabItem), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_slab_pack, dim3((uint32_t)std::min<size_t>(n, 8192)), dim3(256), 0, 0, d_items.as<SlabItem>(), (uint32_t)n,
+                       slab->bytes.as<uint8_t>());
+    K2R_HIP(hipGetLastError());
+    K2R_HIP(d_offs.alloc(n * 8));
+    K2R_HIP(d_lens.alloc(n * 8));
+    K2R_HIP(hipMemcpy(d_offs.p, offs.data(), n * 8, hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_lens.p, lens, n * 8, hipMemcpyHostToDevice));
+    K2R_HIP(d_meta.alloc(n * sizeof(OpenMeta)));
+    const uint32_t pgrid = (uint32_t)((n + 63) / 64);
+    // pass 1: instants per chunk
+    hipLaunchKernelGGL(k_parse_chunks, dim3(pgrid), dim3(64), 0, 0, slab->bytes.as<uint8_t>(), d_offs.as<uint64_t>(), d_lens.as<uint64_t>(),
+                       (uint32_t)n, (const uint32_t*)nullptr, (InstDesc*)nullptr, (uint8_t*)nullptr, d_meta.as<OpenMeta>(), 1);
+    K2R_HIP(hipGetLastError());
+    std::vector<OpenMeta> meta(n);
+    K2R_HIP(hipMemcpy(meta.data(), d_meta.p, n * sizeof(OpenMeta), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> first(n + 1, 0);
+    for (size_t i = 0; i < n; i++) first[i + 1] = first[i] + (meta[i].ok ? meta[i].n_inst : 0u);
+    const uint32_t total_inst = first[n];
+    if (total_inst == 0) {
+        if (status) for (size_t i = 0; i < n; i++) status[i] = DCDF_ERR_FORMAT;
+        return status ? DCDF_OK : DCDF_ERR_FORMAT;
+    }
+    // pass 2: the descriptors (chunks that failed pass 1 get a zero-length stream: parsed as malformed again, nothing stored)
+    std::vector<uint64_t> lens2(lens, lens + n);
+    for (size_t i = 0; i < n; i++)
+        if (!meta[i].ok) lens2[i] = 0;
+    K2R_HIP(hipMemcpy(d_lens.p, lens2.data(), n * 8, hipMemcpyHostToDevice));
+    K2R_HIP(d_first.alloc((n + 1) * 4));
+    K2R_HIP(hipMemcpy(d_first.p, first.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    K2R_HIP(slab->descs.alloc((size_t)total_inst * sizeof(InstDesc)));
+    K2R_HIP(d_quirk.alloc(total_inst));
+    hipLaunchKernelGGL(k_parse_chunks, dim3(pgrid), dim3(64), 0, 0, slab->bytes.as<uint8_t>(), d_offs.as<uint64_t>(), d_lens.as<uint64_t>(),
+                       (uint32_t)n, d_first.as<uint32_t>(), slab->descs.as<InstDesc>(), d_quirk.as<uint8_t>(), d_meta.as<OpenMeta>(), 0);
+    K2R_HIP(hipGetLastError());
+    std::vector<OpenMeta> meta2(n);
+    K2R_HIP(hipMemcpy(meta2.data(), d_meta.p, n * sizeof(OpenMeta), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> quirk(total_inst);
+    K2R_HIP(hipMemcpy(quirk.data(), d_quirk.p, total_inst, hipMemcpyDeviceToHost));
+    std::vector<InstDesc> descs(total_inst);
+    K2R_HIP(hipMemcpy(descs.data(), slab->descs.p, (size_t)total_inst * sizeof(InstDesc), hipMemcpyDeviceToHost));
+    // side-16 tables for the k = 2 chunks of sidelen 32..256: one slab, one launch
+    const bool want_top = !std::getenv("K2R_NO_TOP_TABLE");
+    std::vector<uint64_t> top_off(n, 0);
+    std::vector<uint32_t> top_g(n, 0);
+    uint64_t squares = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!meta[i].ok || !meta2[i].ok) continue;
+        // the depth the reference computes (k2r_runtime.h ref_sidelen): a stream that disagrees is not a chunk of this format
+        if (meta[i].sidelen != ref_sidelen(std::max(meta[i].rows, meta[i].cols), meta[i].k)) {
+            meta2[i].ok = 0;
+            continue;
+        }
+        if (want_top && meta[i].k == 2 && meta[i].sidelen >= 32 && meta[i].sidelen <= 256) {
+            top_g[i] = meta[i].sidelen / 16;
+            top_off[i] = squares;
+            squares += (uint64_t)meta[i].n_inst * top_g[i] * top_g[i];
+        }
+    }
+    std::vector<ChunkRef> refs(n);
+    if (squares) {
+        K2R_HIP(slab->top.alloc(squares * sizeof(TopEnt)));
+        K2R_HIP(slab->top_mm.alloc(squares * sizeof(TopMM)));
+    }
+    for (size_t i = 0; i < n; i++) {
+        const bool ok = meta[i].ok && meta2[i].ok;
+        refs[i] = ChunkRef{slab->bytes.as<uint8_t>() + offs[i], slab->descs.as<InstDesc>() + first[i], ok ? meta[i].n_inst : 0u, meta[i].rows,
+                           meta[i].cols, meta[i].fbits, top_g[i] ? slab->top.as<TopEnt>() + top_off[i] : nullptr,
+                           top_g[i] ? slab->top_mm.as<TopMM>() + top_off[i] : nullptr, ok ? top_g[i] : 0u, 0};
+    }
+    K2R_HIP(slab->refs.alloc(n * sizeof(ChunkRef)));
+    K2R_HIP(hipMemcpy(slab->refs.p, refs.data(), n * sizeof(ChunkRef), hipMemcpyHostToDevice));
+    std::vector<uint32_t> ovf(n, 0);
+    if (squares) {
+        std::vector<uint32_t> inst_chunk(total_inst);
+        for (size_t i = 0; i < n; i++)
+            for (uint32_t j = first[i]; j < first[i + 1]; j++) inst_chunk[j] = (uint32_t)i;
+        K2R_HIP(d_ic.alloc((size_t)total_inst * 4));
+        K2R_HIP(hipMemcpy(d_ic.p, inst_chunk.data(), (size_t)total_inst * 4, hipMemcpyHostToDevice));
+        K2R_HIP(d_ovf.alloc(n * 4));
+        K2R_HIP(hipMemset(d_ovf.p, 0, n * 4));
+        hipLaunchKernelGGL(k_top_table_batch, dim3(total_inst), dim3(64), 0, 0, slab->refs.as<ChunkRef>(), d_ic.as<uint32_t>(), d_first.as<uint32_t>(),
+                           d_ovf.as<uint32_t>());
+        K2R_HIP(hipGetLastError());
+        K2R_HIP(hipMemcpy(ovf.data(), d_ovf.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    K2R_HIP(hipDeviceSynchronize());
+    int first_err = DCDF_OK;
+    for (size_t i = 0; i < n; i++) {
+        const bool ok = meta[i].ok && meta2[i].ok;
+        if (status) status[i] = ok ? DCDF_OK : DCDF_ERR_FORMAT;
+        if (!ok) {
+            if (first_err == DCDF_OK) first_err = DCDF_ERR_FORMAT;
+            continue;
+        }
+        std::unique_ptr<dcdf_chunk> c(new (std::nothrow) dcdf_chunk());
+        if (!c) return DCDF_ERR_NOMEM;
+        c->descs.assign(descs.begin() + first[i], descs.begin() + first[i + 1]);
+        c->instants = meta[i].n_inst;
+        c->rows = meta[i].rows;
+        c->cols = meta[i].cols;
+        c->n_blocks = meta[i].n_blocks;
+        c->encoding = (int32_t)meta[i].encoding;
+        c->fbits = meta[i].fbits;
+        c->len = (size_t)lens[i];
+        c->narrow32 = meta2[i].narrow32 != 0;
+        c->search_quirk.assign(quirk.begin() + first[i], quirk.begin() + first[i + 1]);
+        c->top_g = (top_g[i] && !ovf[i]) ? top_g[i] : 0;
+        c->p_bytes = refs[i].bytes;
+        c->p_descs = refs[i].descs;
+        c->p_top = refs[i].top;
+        c->p_top_mm = refs[i].top_mm;
+        c->store = slab;
+        out[i] = c.release();
+    }
+    return status ? DCDF_OK : first_err;
+}
 extern "C" int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* encoding, uint32_t* fractional_bits,
                                uint32_t* n_blocks) {
     if (!h) return DCDF_ERR_BAD_ARG;
@@ -1106,9 +1373,22 @@ extern "C" int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* 
     return DCDF_OK;
 }
 
+// Byte range of every instant's Snapshot / Log inside the chunk (off[i] .. off[i + 1]; off has instants + 1 entries) and
+// the instant of the snapshot its block starts with: what a decode of instant i can touch at most (decode path:
+// "encoded bytes of the touched chunks' touched structures").  Host metadata only.
+extern "C" int dcdf_chunk_instant_layout(const dcdf_chunk* h, uint64_t* off, uint32_t* snapshot_of) {
+    if (!h || !off) return DCDF_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < h->instants; i++) {
+        off[i] = (uint64_t)h->descs[i].T.idx_off - 8 - 13;  // BitMap header (len, k) and the 13-byte instant header before it
+        if (snapshot_of) snapshot_of[i] = h->descs[i].snap;
+    }
+    off[h->instants] = h->len;
+    return DCDF_OK;
+}
+
 static ChunkRef make_ref(const dcdf_chunk* h) {
-    return ChunkRef{h->d_bytes.as<uint8_t>(), h->d_descs.as<InstDesc>(), h->instants, h->rows, h->cols, h->fbits,
-                    h->top_g ? h->d_top.as<TopEnt>() : nullptr, h->top_g ? h->d_top_mm.as<TopMM>() : nullptr, h->top_g, 0};
+    return ChunkRef{h->p_bytes, h->p_descs, h->instants, h->rows, h->cols, h->fbits,
+                    h->top_g ? (const TopEnt*)h->p_top : nullptr, h->top_g ? (const TopMM*)h->p_top_mm : nullptr, h->top_g, 0};
 }
 // geom::Cube::new reorders reversed bounds (geom.rs:83-103)
 static dcdf_cube norm_cube(const dcdf_cube& c) {
@@ -1123,7 +1403,47 @@ static bool cube_in(const dcdf_chunk* h, const dcdf_cube& c) {  // mmarray.rs:21
 }
 
 // ---- point queries --------------------------------------------------------------------------------------
+// A host thread's page of pinned, device-visible memory: single get / short fill_cell calls put their queries there and the
+// kernel writes the answers there -- no allocation and no explicit copy per call (the round-1 form did three hipMalloc, two
+// H2D copies and one D2H copy per cell).
+namespace {
+struct PinnedPage {
+    static constexpr size_t kPoints = 1024;
+    ChunkRef* ref = nullptr;  // [1]
+    PointQuery* q = nullptr;  // [kPoints]
+    int64_t* out = nullptr;   // [kPoints]
+    void* base = nullptr;
+    bool init() {
+        if (base) return true;
+        const size_t bytes = 256 + kPoints * (sizeof(PointQuery) + 8);
+        if (hipHostMalloc(&base, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            base = nullptr;
+            return false;
+        }
+        ref = (ChunkRef*)base;
+        q = (PointQuery*)((uint8_t*)base + 256);
+        out = (int64_t*)((uint8_t*)base + 256 + kPoints * sizeof(PointQuery));
+        return true;
+    }
+    ~PinnedPage() {
+        if (base) (void)hipHostFree(base);
+    }
+};
+thread_local PinnedPage g_page;
+}  // namespace
+
 static int run_points(const dcdf_chunk* h, const std::vector<PointQuery>& pq, int64_t* out) {
+    const uint32_t n = (uint32_t)pq.size();
+    if (n <= PinnedPage::kPoints && g_page.init()) {
+        *g_page.ref = make_ref(h);
+        std::memcpy(g_page.q, pq.data(), n * sizeof(PointQuery));
+        hipLaunchKernelGGL(k_get, dim3((n + 255) / 256), dim3(256), 0, 0, g_page.ref, g_page.q, n, g_page.out);
+        K2R_HIP(hipGetLastError());
+        K2R_HIP(hipStreamSynchronize(0));
+        std::memcpy(out, g_page.out, n * 8ull);
+        return DCDF_OK;
+    }
     const ChunkRef ref = make_ref(h);
     DevBuf d_ref, d_q, d_o;
     K2R_HIP(d_ref.alloc(sizeof(ref)));
@@ -1131,7 +1451,6 @@ static int run_points(const dcdf_chunk* h, const std::vector<PointQuery>& pq, in
     K2R_HIP(d_q.alloc(pq.size() * sizeof(PointQuery)));
     K2R_HIP(hipMemcpy(d_q.p, pq.data(), pq.size() * sizeof(PointQuery), hipMemcpyHostToDevice));
     K2R_HIP(d_o.alloc(pq.size() * 8));
-    const uint32_t n = (uint32_t)pq.size();
     hipLaunchKernelGGL(k_get, dim3((n + 255) / 256), dim3(256), 0, 0, d_ref.as<ChunkRef>(), d_q.as<PointQuery>(), n,
                        d_o.as<int64_t>());
     K2R_HIP(hipGetLastError());
@@ -1153,6 +1472,100 @@ extern "C" int dcdf_chunk_fill_cell(const dcdf_chunk* h, uint32_t start, uint32_
     std::vector<PointQuery> pq;
     for (uint32_t i = start; i < end; i++) pq.push_back(PointQuery{0, i, row, col});
     return run_points(h, pq, out);
+}
+
+static void dedup_chunks(dcdf_chunk* const* chunks, size_t nq, std::vector<uint32_t>& idx, std::vector<const dcdf_chunk*>& uniq);
+static int upload_refs(dcdf_chunk* const* chunks, const std::vector<uint32_t>& uniq_of_query, size_t nuniq,
+                       const std::vector<const dcdf_chunk*>& uniq, DevBuf& d_refs);
+// many (chunk, point) pairs -- or (chunk, cell series) -- in ONE launch (Superchunk::get / fill_cell route many points,
+// superchunk.rs:313-400); at[] = output position of each point, or null for "in order"
+static int run_points_multi(dcdf_chunk* const* chunks, size_t nchunks_q, const std::vector<uint32_t>& chunk_of_point,
+                            std::vector<PointQuery>& pq, const std::vector<uint64_t>* at, uint64_t out_elems, int64_t* out, int out_mem,
+                            float* kernel_ms) {
+    std::vector<uint32_t> cidx;
+    std::vector<const dcdf_chunk*> uniq;
+    dedup_chunks(chunks, nchunks_q, cidx, uniq);
+    for (size_t i = 0; i < pq.size(); i++) pq[i].chunk = cidx[chunk_of_point[i]];
+    DevBuf d_refs, d_q, d_at, d_o;
+    int rc = upload_refs(chunks, cidx, uniq.size(), uniq, d_refs);
+    if (rc != DCDF_OK) return rc;
+    const uint32_t n = (uint32_t)pq.size();
+    K2R_HIP(d_q.alloc(pq.size() * sizeof(PointQuery)));
+    K2R_HIP(hipMemcpy(d_q.p, pq.data(), pq.size() * sizeof(PointQuery), hipMemcpyHostToDevice));
+    int64_t* dst = out;
+    if (out_mem == DCDF_MEM_HOST) {
+        K2R_HIP(d_o.alloc(out_elems * 8));
+        dst = d_o.as<int64_t>();
+    }
+    if (at) {
+        K2R_HIP(d_at.alloc(at->size() * 8));
+        K2R_HIP(hipMemcpy(d_at.p, at->data(), at->size() * 8, hipMemcpyHostToDevice));
+    }
+    EventPair ev;
+    K2R_HIP(ev.create());
+    K2R_HIP(hipEventRecord(ev.e0, 0));
+    if (at) hipLaunchKernelGGL(k_get_at, dim3((n + 255) / 256), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_q.as<PointQuery>(), n, dst, d_at.as<uint64_t>());
+    else hipLaunchKernelGGL(k_get, dim3((n + 255) / 256), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_q.as<PointQuery>(), n, dst);
+    K2R_HIP(hipEventRecord(ev.e1, 0));
+    K2R_HIP(hipGetLastError());
+    if (out_mem == DCDF_MEM_HOST) K2R_HIP(hipMemcpy(out, d_o.p, out_elems * 8, hipMemcpyDeviceToHost));
+    else K2R_HIP(hipDeviceSynchronize());
+    float ms = 0.f;
+    K2R_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    if (kernel_ms) *kernel_ms = ms;
+    return DCDF_OK;
+}
+extern "C" int dcdf_query_get_batch(dcdf_chunk* const* chunks, const uint32_t* points, size_t n, int64_t* out, int out_mem,
+                                    float* kernel_ms) {
+    if (!chunks || !points || !out || n == 0 || n > 0x7fffffffu || (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE)) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    std::vector<PointQuery> pq(n);
+    std::vector<uint32_t> cop(n);
+    for (size_t i = 0; i < n; i++) {
+        const dcdf_chunk* h = chunks[i];
+        if (!h) return DCDF_ERR_BAD_ARG;
+        const uint32_t t = points[3 * i], r = points[3 * i + 1], c = points[3 * i + 2];
+        if (t >= h->instants || r >= h->rows || c >= h->cols) return DCDF_ERR_BOUNDS;
+        pq[i] = PointQuery{0, t, r, c};
+        cop[i] = (uint32_t)i;
+    }
+    return run_points_multi(chunks, n, cop, pq, nullptr, n, out, out_mem, kernel_ms);
+}
+extern "C" int dcdf_query_fill_cell_batch(dcdf_chunk* const* chunks, const uint32_t* cells, size_t n, int64_t* out,
+                                          const uint64_t* out_offset, int out_mem, float* kernel_ms) {
+    if (!chunks || !cells || !out || !out_offset || n == 0 || n > 0x7fffffffu || (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE)) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    std::vector<PointQuery> pq;
+    std::vector<uint32_t> cop;
+    std::vector<uint64_t> at;
+    uint64_t hi = 0;
+    for (size_t i = 0; i < n; i++) {
+        const dcdf_chunk* h = chunks[i];
+        if (!h) return DCDF_ERR_BAD_ARG;
+        uint32_t a = cells[4 * i], b = cells[4 * i + 1];
+        const uint32_t r = cells[4 * i + 2], c = cells[4 * i + 3];
+        if (a > b) std::swap(a, b);
+        if (b > h->instants || r >= h->rows || c >= h->cols) return DCDF_ERR_BOUNDS;
+        for (uint32_t t = a; t < b; t++) {
+            pq.push_back(PointQuery{0, t, r, c});
+            cop.push_back((uint32_t)i);
+            at.push_back(out_offset[i] + (t - a));
+        }
+        hi = std::max<uint64_t>(hi, out_offset[i] + (b - a));
+    }
+    if (pq.empty()) return DCDF_OK;
+    if (pq.size() > 0x7fffffffu) return DCDF_ERR_CAPACITY;
+    if (out_mem == DCDF_MEM_HOST) {  // dense staging on the device, then scattered into the caller's array
+        std::vector<uint64_t> dense(pq.size());
+        for (size_t i = 0; i < dense.size(); i++) dense[i] = i;
+        std::vector<int64_t> tmp(pq.size());
+        const int rc = run_points_multi(chunks, n, cop, pq, nullptr, pq.size(), tmp.data(), DCDF_MEM_HOST, kernel_ms);
+        if (rc != DCDF_OK) return rc;
+        for (size_t i = 0; i < tmp.size(); i++) out[at[i]] = tmp[i];
+        (void)hi;
+        return DCDF_OK;
+    }
+    return run_points_multi(chunks, n, cop, pq, &at, hi, out, DCDF_MEM_DEVICE, kernel_ms);
 }
 
 
@@ -1276,7 +1689,7 @@ static void dedup_chunks(dcdf_chunk* const* chunks, size_t nq, std::vector<uint3
 
 static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper,
                        size_t nq, uint32_t* out, size_t cap, uint64_t* counts, uint64_t* offsets, size_t* total_out,
-                       float* kernel_ms) {
+                       float* kernel_ms, int out_mem = DCDF_MEM_HOST) {
     std::vector<uint32_t> cidx;
     std::vector<const dcdf_chunk*> uniq;
     dedup_chunks(chunks, nq, cidx, uniq);
@@ -1394,14 +1807,16 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         if (run > 0) {
             K2R_HIP(d_offs.alloc(items.size() * 8));
             K2R_HIP(hipMemcpy(d_offs.p, item_offs.data(), items.size() * 8, hipMemcpyHostToDevice));
-            K2R_HIP(d_out.alloc(run * 12));
+            const bool to_dev = out_mem == DCDF_MEM_DEVICE;  // the triples stay where the emit kernel writes them
+            if (!to_dev) K2R_HIP(d_out.alloc(run * 12));
             K2R_HIP(hipEventRecord(e0, 0));
             hipLaunchKernelGGL(k_search_emit, dim3((ni + 63) / 64), dim3(64), 0, 0, d_qs.as<WinQuery>(),
                                d_items.as<SearchItem>(), ni, d_bits.as<uint32_t>(), d_wbits.as<uint32_t>(), d_offs.as<uint64_t>(),
-                               d_out.as<uint32_t>());
+                               to_dev ? out : d_out.as<uint32_t>());
             K2R_HIP(hipEventRecord(e1, 0));
             K2R_HIP(hipGetLastError());
-            K2R_HIP(hipMemcpy(out, d_out.p, run * 12, hipMemcpyDeviceToHost));
+            if (to_dev) K2R_HIP(hipDeviceSynchronize());
+            else K2R_HIP(hipMemcpy(out, d_out.p, run * 12, hipMemcpyDeviceToHost));
             K2R_HIP(hipEventElapsedTime(&ms, e0, e1));
             ms_total += ms;
         }
@@ -1434,10 +1849,17 @@ extern "C" int dcdf_query_search_batch(dcdf_chunk* const* chunks, const dcdf_cub
     return search_impl(chunks, cubes, lower, upper, nq, out, cap, counts, offsets, &total, kernel_ms);
 }
 
-extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcdf_cube* cubes, size_t nq, int64_t* out,
-                                            const uint64_t* out_offset, float* kernel_ms) {
+// out_dtype: the element type written (MMBuffer3::set conversion of the stored value, mmbuffer.rs:292-299: i32 / i64 as is,
+// f32 / f64 through from_fixed); out_mem: `out` is host or DEVICE memory -- a device `out` is written by the decode kernel
+// itself at out_offset[q] (elements), nothing crosses PCIe
+static int fill_window_batch_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, size_t nq, void* out, int32_t out_dtype, int out_mem,
+                                  const uint64_t* out_offset, float* kernel_ms) {
     if (!chunks || !cubes || !out || !out_offset || nq == 0) return DCDF_ERR_BAD_ARG;
+    if (out_dtype != DCDF_I32 && out_dtype != DCDF_I64 && out_dtype != DCDF_F32 && out_dtype != DCDF_F64) return DCDF_ERR_BAD_ARG;
+    if (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE) return DCDF_ERR_BAD_ARG;
     if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    const size_t es = (out_dtype == DCDF_I32 || out_dtype == DCDF_F32) ? 4 : 8;
+    const bool to_dev = out_mem == DCDF_MEM_DEVICE;
     std::vector<uint32_t> cidx;
     std::vector<const dcdf_chunk*> uniq;
     dedup_chunks(chunks, nq, cidx, uniq);
@@ -1454,7 +1876,7 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
         Q = WinQuery{};
         Q.chunk = cidx[q];
         Q.start = c.start; Q.end = c.end; Q.top = c.top; Q.bottom = c.bottom; Q.left = c.left; Q.right = c.right;
-        Q.out_off = total;
+        Q.out_off = to_dev ? out_offset[q] : total;
         dense = dense && out_offset[q] == total + out_offset[0];
         total += (uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left);
     }
@@ -1464,7 +1886,8 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
     if (rc != DCDF_OK) return rc;
     K2R_HIP(d_qs.alloc(nq * sizeof(WinQuery)));
     K2R_HIP(hipMemcpy(d_qs.p, qs.data(), nq * sizeof(WinQuery), hipMemcpyHostToDevice));
-    K2R_HIP(d_o.alloc(total * 8));
+    if (!to_dev) K2R_HIP(d_o.alloc(total * es));
+    void* const d_dst = to_dev ? out : d_o.p;
     EventPair ev;
     K2R_HIP(ev.create());
     bool all_wave = true, all_node = true;
@@ -1480,28 +1903,50 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
             const dcdf_cube c{qs[q].start, qs[q].end, qs[q].top, qs[q].bottom, qs[q].left, qs[q].right};
             window_items(qs[q].chunk, c, qs[q].out_off, items, all_node);
         }
-        rc = launch_window_items(d_refs, items, d_o.p, (int32_t)DCDF_I64, ev.e0, ev.e1, all_node, all_narrow);
+        rc = launch_window_items(d_refs, items, d_dst, out_dtype, ev.e0, ev.e1, all_node, all_narrow);
         if (rc != DCDF_OK) return rc;
     } else {
+        // arities beyond the wave walk (k * k > 64): per-cell descents, int64 only
+        if (out_dtype != DCDF_I64) return DCDF_ERR_UNSUPPORTED;
         const uint32_t grid = (uint32_t)std::min<size_t>(nq, 1u << 20);
         K2R_HIP(hipEventRecord(ev.e0, 0));
         hipLaunchKernelGGL(k_fill_window, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
-                           (uint32_t)nq, d_o.p, (int32_t)DCDF_I64, (int64_t)0, (int64_t)0, (int64_t)0, 0);
+                           (uint32_t)nq, d_dst, (int32_t)DCDF_I64, (int64_t)0, (int64_t)0, (int64_t)0, 0);
         K2R_HIP(hipEventRecord(ev.e1, 0));
         K2R_HIP(hipGetLastError());
+        K2R_HIP(hipDeviceSynchronize());
     }
-    if (dense) {  // the usual case: windows back to back in query order -> one copy straight into the caller's array
-        K2R_HIP(hipMemcpy(out + out_offset[0], d_o.p, total * 8, hipMemcpyDeviceToHost));
+    if (to_dev) {
+        // (already in place)
+    } else if (dense) {  // the usual case: windows back to back in query order -> one copy straight into the caller's array
+        K2R_HIP(hipMemcpy((uint8_t*)out + out_offset[0] * es, d_o.p, total * es, hipMemcpyDeviceToHost));
     } else {
-        std::vector<int64_t> tmp(total);
-        K2R_HIP(hipMemcpy(tmp.data(), d_o.p, total * 8, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> tmp(total * es);
+        K2R_HIP(hipMemcpy(tmp.data(), d_o.p, total * es, hipMemcpyDeviceToHost));
         for (size_t q = 0; q < nq; q++) {
             const uint64_t cells = (uint64_t)(qs[q].end - qs[q].start) * (qs[q].bottom - qs[q].top) * (qs[q].right - qs[q].left);
-            if (cells) std::memcpy(out + out_offset[q], tmp.data() + qs[q].out_off, cells * 8);
+            if (cells) std::memcpy((uint8_t*)out + out_offset[q] * es, tmp.data() + qs[q].out_off * es, cells * es);
         }
     }
     float ms = 0.f;
     K2R_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     if (kernel_ms) *kernel_ms = ms;
     return DCDF_OK;
+}
+extern "C" int dcdf_query_search_batch_mem(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const int64_t* lower,
+                                           const int64_t* upper, size_t nq, uint32_t* out, size_t cap, int out_mem,
+                                           uint64_t* counts, uint64_t* offsets, float* kernel_ms) {
+    if (!chunks || !cubes || !lower || !upper || !counts || !offsets || nq == 0 || (!out && cap)) return DCDF_ERR_BAD_ARG;
+    if (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    size_t total = 0;
+    return search_impl(chunks, cubes, lower, upper, nq, out, cap, counts, offsets, &total, kernel_ms, out_mem);
+}
+extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcdf_cube* cubes, size_t nq, int64_t* out,
+                                            const uint64_t* out_offset, float* kernel_ms) {
+    return fill_window_batch_impl(chunks, cubes, nq, out, (int32_t)DCDF_I64, DCDF_MEM_HOST, out_offset, kernel_ms);
+}
+extern "C" int dcdf_query_fill_window_batch_typed(dcdf_chunk* const* chunks, const dcdf_cube* cubes, size_t nq, void* out,
+                                                  int32_t out_dtype, int out_mem, const uint64_t* out_offset, float* kernel_ms) {
+    return fill_window_batch_impl(chunks, cubes, nq, out, out_dtype, out_mem, out_offset, kernel_ms);
 }

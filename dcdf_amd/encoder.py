@@ -36,6 +36,26 @@ class Encoder:
         L.check(L.lib().dcdf_encoder_result(self._h, C.c_size_t(i), C.byref(st), C.byref(ln), C.byref(ns), C.byref(nl), None))
         return st.value, ln.value, ns.value, nl.value
 
+    def device_bytes(self, i):
+        """(device pointer, length) of tile i's Chunk::write_to bytes where the encoder left them in HBM."""
+        st, ln = C.c_int32(), C.c_uint64()
+        p = C.POINTER(C.c_uint8)()
+        L.check(L.lib().dcdf_encoder_result(self._h, C.c_size_t(i), C.byref(st), C.byref(ln), None, None, C.byref(p)))
+        if st.value != 0:
+            raise L.DcdfError(st.value, "tile %d" % i)
+        return C.cast(p, C.c_void_p).value, ln.value
+
+    def open_chunks(self, indices=None):
+        """dcdf_chunk_open_batch over this session's device buffers: the encoded chunks become queryable without ever
+        leaving HBM (parsed on the device, all side-16 tables in one launch).  Returns [dcdf_amd.Chunk]."""
+        from .chunk import Chunk
+        idx = list(range(self.n)) if indices is None else list(indices)
+        ptrs = (C.c_void_p * len(idx))()
+        lens = (C.c_uint64 * len(idx))()
+        for j, i in enumerate(idx):
+            ptrs[j], lens[j] = self.device_bytes(i)
+        return Chunk.open_batch_device(ptrs, lens, fetch=lambda j: self.fetch(idx[j]))
+
     def fetch(self, i):
         st, ln, _, _ = self.result(i)
         if st != 0:

@@ -164,6 +164,11 @@ void dcdf_chunk_close(dcdf_chunk* h);
 int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* encoding, uint32_t* fractional_bits,
                     uint32_t* n_blocks);
 
+/* Byte offsets of the instants' Snapshots / Logs inside the chunk (off[instants + 1], the last = the chunk's length) and,
+ * per instant, the instant of its block's snapshot (may be NULL): the encoded bytes a decode of instant i can touch are
+ * [off[i], off[i + 1]) and the snapshot's range -- the decode path's algorithmic bytes. */
+int dcdf_chunk_instant_layout(const dcdf_chunk* h, uint64_t* off, uint32_t* snapshot_of);
+
 /* Replaces `Chunk::get` (chunk.rs:127-131): stored i64 value (fixed-point for float chunks). */
 int dcdf_chunk_get(const dcdf_chunk* h, uint32_t instant, uint32_t row, uint32_t col, int64_t* out);
 /* Replaces `Chunk::fill_cell` (chunk.rs:135-148): out[end-start] stored i64 values (host). */
@@ -186,6 +191,34 @@ int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcdf_cube* cub
 int dcdf_query_search_batch(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const int64_t* lower,
                             const int64_t* upper, size_t nq, uint32_t* out, size_t cap, uint64_t* counts,
                             uint64_t* offsets, float* kernel_ms);
+
+/* The same with a typed result and a result that may stay on the device: out_dtype = DCDF_I32 / I64 / F32 / F64 is the
+ * element type written (MMBuffer3::set, mmbuffer.rs:292-299: integers as stored, floats through from_fixed, fixed.rs:81-86);
+ * out_mem = DCDF_MEM_DEVICE: `out` is device memory, the decode kernel writes window q at out + out_offset[q] (ELEMENTS of
+ * out_dtype) itself and nothing crosses PCIe.  An int32 result of int32 chunks moves half the bytes of the i64 form. */
+int dcdf_query_fill_window_batch_typed(dcdf_chunk* const* chunks, const dcdf_cube* cubes, size_t nq, void* out,
+                                       int32_t out_dtype, int out_mem, const uint64_t* out_offset, float* kernel_ms);
+/* dcdf_query_search_batch whose triples may stay on the device (out_mem = DCDF_MEM_DEVICE: `out` is device memory of `cap`
+ * triples); counts / offsets are always host arrays. */
+int dcdf_query_search_batch_mem(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper,
+                                size_t nq, uint32_t* out, size_t cap, int out_mem, uint64_t* counts, uint64_t* offsets,
+                                float* kernel_ms);
+/* Many point / cell-series queries in ONE launch -- what Superchunk::get / fill_cell (superchunk.rs:313-400) and the
+ * Span / Dataset layers above them route to their chunks.  points = n x {instant, row, col}; out[i] = the stored i64 value
+ * of point i of chunks[i] (Chunk::get, chunk.rs:127-131).  cells = n x {start, end, row, col}; series i goes to
+ * out + out_offset[i] (Chunk::fill_cell, chunk.rs:135-148).  out_mem as above. */
+int dcdf_query_get_batch(dcdf_chunk* const* chunks, const uint32_t* points, size_t n, int64_t* out, int out_mem,
+                         float* kernel_ms);
+int dcdf_query_fill_cell_batch(dcdf_chunk* const* chunks, const uint32_t* cells, size_t n, int64_t* out,
+                               const uint64_t* out_offset, int out_mem, float* kernel_ms);
+/* Opens n chunks at once.  mem = DCDF_MEM_HOST: as n calls of dcdf_chunk_open.  mem = DCDF_MEM_DEVICE: bytes[i] are DEVICE
+ * pointers, e.g. dcdf_encoder_result's `device_bytes` -- the streams are packed into one slab, parsed on the device (one
+ * thread per chunk, bounds-checked) and the side-16 tables of all their instants are built by one launch; nothing is copied
+ * to the host but the per-chunk metadata.  Device input is trusted to come from this library's encoders (the popcount
+ * cross-checks dcdf_chunk_open makes on untrusted streams are not repeated).  status (may be NULL): one code per chunk;
+ * out[i] = NULL where it is not 0.  Every handle is closed with dcdf_chunk_close; the slab goes with the last one. */
+int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t* lens, size_t n, int mem, dcdf_chunk** out,
+                          int32_t* status);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 /* fixed.rs:96-159 + mmbuffer.rs:596-613: per-tile suggest_fraction on the device; out_round = 1 for

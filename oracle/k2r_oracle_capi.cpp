@@ -2,6 +2,7 @@
 // C ABI over the CPU restatement so that tests (ctypes) and bench.py's
 // cpu_baseline leg can call it.  Never linked into libdcdf_k2r.so.
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 
 #include "k2r_oracle.hpp"
@@ -446,6 +447,54 @@ uint64_t orc_sidelen(uint32_t rows, uint32_t cols, int k) { return compute_sidel
 // Builds `n_chunks` chunks (each [instants, rows, cols], dense, consecutive in `base`) serially on the
 // calling thread, exactly as the reference does (superchunk.rs:166-188), and returns elapsed seconds
 // for build + serialize.  Optionally returns a 64-bit FNV-1a over all serialized bytes.
+// Timed batches of chunk-level queries for the decode-path CPU baseline (tools/bench_query.py): query q =
+// Chunk::fill_window (chunk.rs:152-158, into an int32 array as MMBuffer3::set does for I32 chunks) or Chunk::iter_search
+// (chunk.rs:213-229) of chunks[q] on cubes[6 q ..]; `threads` workers take the queries in strides.  The clock runs inside.
+int orc_bench_queries(void* const* chunks, const uint32_t* cubes, const int64_t* lower, const int64_t* upper, size_t n, int search,
+                      int threads, double* seconds, uint64_t* work) {
+    ORC_TRY
+    if (threads < 1) threads = 1;
+    std::vector<uint64_t> acc((size_t)threads, 0);
+    std::vector<int> failed((size_t)threads, 0);
+    auto body = [&](int t) {
+        try {
+            std::vector<int32_t> out;
+            for (size_t q = (size_t)t; q < n; q += (size_t)threads) {
+                const Chunk& c = ((OrcChunk*)chunks[q])->chunk;
+                const uint32_t* u = cubes + 6 * q;
+                Cube cube(u[0], u[1], u[2], u[3], u[4], u[5]);
+                if (search) {
+                    acc[t] += c.search(cube, lower[q], upper[q]).size();
+                } else {
+                    const size_t wr = cube.bottom - cube.top, wc = cube.right - cube.left, wt = cube.end - cube.start;
+                    out.resize(wt * wr * wc);
+                    c.fill_window(cube, [&](size_t i, size_t r, size_t cc, int64_t v) { out[(i * wr + r) * wc + cc] = (int32_t)v; });
+                    acc[t] += out.size();
+                }
+            }
+        } catch (...) {
+            failed[t] = 1;
+        }
+    };
+    auto t0 = std::chrono::steady_clock::now();
+    if (threads == 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++) th.emplace_back(body, t);
+        for (auto& x : th) x.join();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    uint64_t tot = 0;
+    for (int t = 0; t < threads; t++) {
+        if (failed[t]) return -101;
+        tot += acc[t];
+    }
+    *seconds = std::chrono::duration<double>(t1 - t0).count();
+    *work = tot;
+    return 0;
+    ORC_CATCH
+}
+
 int orc_bench_build(const void* base, int encoding, uint32_t n_chunks, uint32_t instants, uint32_t rows, uint32_t cols,
                     int k, double* seconds, uint64_t* total_bytes, uint64_t* fnv) {
     ORC_TRY

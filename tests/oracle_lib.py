@@ -326,3 +326,19 @@ def bench_build(a4, k=2, native=False):
                                  C.c_uint32(a4.shape[1]), C.c_uint32(a4.shape[2]), C.c_uint32(a4.shape[3]), k,
                                  C.byref(sec), C.byref(tb), C.byref(h)))
     return sec.value, tb.value, h.value
+
+
+def bench_queries(chunks, cubes, lower=None, upper=None, threads=1, native=False):
+    """Timed batch of chunk-level queries on the oracle (orc_bench_queries): chunks = [oracle Chunk] per query, cubes = uint32[n, 6];
+    lower/upper given -> iter_search, else fill_window.  Returns (seconds, decoded cells or hits)."""
+    n = len(chunks)
+    hs = (C.c_void_p * n)(*[c._h for c in chunks])
+    cub = np.ascontiguousarray(np.asarray(cubes, dtype=np.uint32).reshape(n, 6))
+    search = lower is not None
+    lo = np.ascontiguousarray(np.asarray(lower if search else np.zeros(n), dtype=np.int64))
+    hi = np.ascontiguousarray(np.asarray(upper if search else np.zeros(n), dtype=np.int64))
+    sec, work = C.c_double(), C.c_uint64()
+    Lb = (native_lib() if native else None) or lib()
+    _check(Lb.orc_bench_queries(hs, C.c_void_p(cub.ctypes.data), C.c_void_p(lo.ctypes.data), C.c_void_p(hi.ctypes.data), C.c_size_t(n),
+                                int(search), int(threads), C.byref(sec), C.byref(work)))
+    return sec.value, work.value

@@ -225,3 +225,19 @@ def test_out_capacity_retry_and_session_reuse(dc):
         enc.close()
         for b in bufs:
             b.free()
+
+
+def test_config4_one_million_queries_full_size(dc):
+    """BASELINE configs[4] at full size: 1M random get_window + search_window queries against the encoded 4096x4096x365 raster
+    (tools/bench_query.py: chunks opened from the encoder's device buffers, typed device-resident results), 80 reassembled
+    answers per kind checked against the synthetic model cell by cell / hit by hit, and the totals against the size-independent
+    facts of the workload (every query is answered; decoded cells == the cubes' volumes)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_query", os.path.join(os.path.dirname(HERE), "tools", "bench_query.py"))
+    bq = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bq)
+    res = bq.run(queries=1000000, batch=250000, segments=12, check=20, cpu_sample=0, host_results=False)
+    assert res["config"]["chunks"] == 3072 and res["config"]["answers_checked_vs_model"] == 160
+    assert res["fill_window"]["queries"] == 500000 and res["search_window"]["queries"] == 500000
+    assert res["fill_window"]["cells"] > 2e9 and res["search_window"]["hits"] > 1e8
+    assert res["open"]["seconds"] < 5.0

@@ -312,3 +312,89 @@ def test_malformed_chunks_are_rejected_at_open(dc):
         c.iter_search(dc.Cube(0, shp[0], 0, shp[1], 0, shp[2]), -5, 5)
         c.close()
     assert rejected >= 10 and opened > 0
+
+
+def test_batched_points_typed_windows_and_device_open(dc):
+    """The query entry points that do not defeat the kernels (include/dcdf_k2r.h): chunks opened straight from an encoder
+    session's device buffers (dcdf_chunk_open_batch: parsed on the device, all side-16 tables in one launch), many gets /
+    cell series in one launch, typed and device-resident window results.  Everything against the oracle's Chunk and the
+    raw cells."""
+    import ctypes as C
+    from dcdf_amd import synth, _lib as L
+    from dcdf_amd.encoder import DeviceBuffer, Encoder
+    arrays = [synth.cells(0xDCDF0005 + i, 0, T, 0, r, 0, c, np.int32) for i, (T, r, c) in enumerate([(9, 256, 256), (5, 200, 256), (7, 64, 64), (3, 16, 16)])]
+    arrays.append(np.zeros((4, 64, 64), dtype=np.int32) + 5)                      # single-node instants (no table walk)
+    arrays.append((synth.cells(0xDCDF0007, 0, 4, 0, 64, 0, 64, np.int64)))         # int64 chunk
+    bufs, descs = [], []
+    for a in arrays:
+        b = DeviceBuffer(a.nbytes)
+        b.write(0, a)
+        bufs.append(b)
+        descs.append((b.ptr, L.DCDF_I32 if a.dtype == np.int32 else L.DCDF_I64, tuple(s // a.itemsize for s in a.strides), a.shape))
+    enc = Encoder(descs, k=2)
+    enc.run()
+    chunks = enc.open_chunks()
+    refs = [O.chunk_build(a) for a in arrays]
+    rng = np.random.default_rng(11)
+    for c, a, ref in zip(chunks, arrays, refs):
+        assert c.shape() == list(a.shape) and c.write_to() == ref
+        np.testing.assert_array_equal(c.fill_window(dc.Cube(0, a.shape[0], 0, a.shape[1], 0, a.shape[2])), a)
+        lo, hi = int(np.percentile(a, 30)), int(np.percentile(a, 45))
+        got = set(map(tuple, c.iter_search(dc.Cube(0, a.shape[0], 1, a.shape[1], 0, a.shape[2] - 1), lo, hi).tolist()))
+        want = set(map(tuple, O.Chunk(ref).search(0, a.shape[0], 1, a.shape[1], 0, a.shape[2] - 1, lo, hi).tolist()))
+        assert got == want
+    # many points over many chunks, one launch
+    which = rng.integers(0, len(arrays), size=500)
+    pts = np.array([[rng.integers(0, arrays[w].shape[0]), rng.integers(0, arrays[w].shape[1]), rng.integers(0, arrays[w].shape[2])] for w in which])
+    got = dc.get_batch([chunks[w] for w in which], pts)
+    want = np.array([int(arrays[w][t, r, c]) for w, (t, r, c) in zip(which, pts)])
+    np.testing.assert_array_equal(got, want)
+    assert chunks[0].get(3, 100, 7) == int(arrays[0][3, 100, 7])                   # single get: pinned page, no allocation
+    cells = [(0, arrays[w].shape[0], int(r), int(c)) for w, (_, r, c) in zip(which[:40], pts[:40])]
+    cells[3] = (cells[3][1], 1, cells[3][2], cells[3][3])                          # reversed bounds are swapped (chunk.rs:135)
+    series = dc.fill_cell_batch([chunks[w] for w in which[:40]], cells)
+    for w, (a0, a1, r, c), sr in zip(which[:40], cells, series):
+        lo_, hi_ = min(a0, a1), max(a0, a1)
+        np.testing.assert_array_equal(sr, arrays[w][lo_:hi_, r, c])
+    # typed windows: int32 result of int32 chunks, float64 through from_fixed of an int chunk is not meaningful -> int only
+    cubes = [dc.Cube(1, 4, 10, 90, 5, 70), dc.Cube(0, 5, 0, 200, 100, 256), dc.Cube(2, 3, 60, 64, 0, 64)]
+    flat, off = dc.fill_window_batch([chunks[0], chunks[1], chunks[2]], cubes, dtype=np.int32)
+    assert flat.dtype == np.int32
+    for q, (w, cu) in enumerate(zip([0, 1, 2], cubes)):
+        exp = arrays[w][cu.start:cu.end, cu.top:cu.bottom, cu.left:cu.right]
+        np.testing.assert_array_equal(flat[int(off[q]):int(off[q]) + exp.size].reshape(exp.shape), exp)
+    # the same windows decoded straight into a caller's DEVICE array (nothing crosses PCIe until we look)
+    vol = [c.instants() * c.rows() * c.cols() for c in cubes]
+    doff = np.array([7, 7 + vol[0] + 13, 7 + vol[0] + 13 + vol[1]], dtype=np.uint64)     # arbitrary element offsets
+    dev = DeviceBuffer(int(doff[2] + vol[2]) * 4)
+    dev.write(0, np.full(int(doff[2] + vol[2]), -1, dtype=np.int32))
+    dc.fill_window_batch([chunks[0], chunks[1], chunks[2]], cubes, dtype=np.int32, out_device_ptr=dev.ptr, out_offset=doff)
+    back = dev.read(0, int(doff[2] + vol[2]) * 4, np.int32)
+    assert (back[:7] == -1).all() and (back[7 + vol[0]:7 + vol[0] + 13] == -1).all()
+    for q, (w, cu) in enumerate(zip([0, 1, 2], cubes)):
+        exp = arrays[w][cu.start:cu.end, cu.top:cu.bottom, cu.left:cu.right]
+        np.testing.assert_array_equal(back[int(doff[q]):int(doff[q]) + exp.size].reshape(exp.shape), exp)
+    for c in chunks:
+        c.close()
+    enc.close()
+
+
+def test_open_batch_rejects_garbage_in_device_memory(dc):
+    from dcdf_amd import _lib as L
+    from dcdf_amd.encoder import DeviceBuffer
+    import ctypes as C
+    good = O.chunk_build(np.arange(2 * 16 * 16, dtype=np.int32).reshape(2, 16, 16))
+    blobs = [good, good[:-3], bytes(40), good[:6] + bytes([9]) + good[7:]]
+    bufs = []
+    ptrs = (C.c_void_p * len(blobs))()
+    lens = (C.c_uint64 * len(blobs))()
+    for i, bts in enumerate(blobs):
+        b = DeviceBuffer(len(bts) + 64)
+        b.write(0, np.frombuffer(bts, dtype=np.uint8))
+        bufs.append(b)
+        ptrs[i], lens[i] = b.ptr, len(bts)
+    hs = (C.c_void_p * len(blobs))()
+    st = (C.c_int32 * len(blobs))()
+    L.check(L.lib().dcdf_chunk_open_batch(ptrs, lens, C.c_size_t(len(blobs)), L.MEM_DEVICE, hs, st))
+    assert list(st) == [0, -7, -7, -7] and hs[0] and not hs[1] and not hs[2] and not hs[3]
+    L.lib().dcdf_chunk_close(C.c_void_p(hs[0]))

@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.dcdf_abi_version() == 2
+    assert lib.dcdf_abi_version() == 3
     assert lib.dcdf_strerror(-8).decode().startswith("unsupported")
 
 
