@@ -33,26 +33,22 @@ SEED = 0xDCDF0003
 
 def encode_raster(segments, extent=4096):
     """The bench.py workload (first `segments` time segments), encoded on the device.  Returns (encoder, grid, T)."""
-    import torch
     from dcdf_amd import _lib as L
-    from dcdf_amd.encoder import Encoder, synth_fill
+    from dcdf_amd.encoder import DeviceBuffer, Encoder, synth_fill
     S, nt = 256, extent // 256
     grid = [(seg, i, j) for seg in range(segments) for i in range(nt) for j in range(nt)]
     sizes = [(min(365, 32 * seg + 32) - 32 * seg) * S * S for seg, _, _ in grid]
     offs = np.concatenate([[0], np.cumsum(sizes)])
-    flat = torch.empty((int(offs[-1]),), dtype=torch.int32, device="cuda")
+    flat = DeviceBuffer(int(offs[-1]) * 4)  # (through the C ABI: no torch needed, and none initialised under pytest)
     descs = []
     for (seg, i, j), o, z in zip(grid, offs, sizes):
         t0, t1 = 32 * seg, min(365, 32 * seg + 32)
-        v = flat[int(o):int(o) + z].view(t1 - t0, S, S)
-        synth_fill(v.data_ptr(), L.DCDF_I32, SEED, t0, t1, S * i, S * i + S, S * j, S * j + S)
-        descs.append((v.data_ptr(), L.DCDF_I32, (S * S, S, 1), (t1 - t0, S, S)))
-    torch.cuda.synchronize()
+        ptr = flat.ptr + int(o) * 4
+        synth_fill(ptr, L.DCDF_I32, SEED, t0, t1, S * i, S * i + S, S * j, S * j + S)
+        descs.append((ptr, L.DCDF_I32, (S * S, S, 1), (t1 - t0, S, S)))
     enc = Encoder(descs, k=2)
     enc.run()
-    del flat
-    torch.cuda.empty_cache()
-    return enc, grid, min(365, 32 * segments)
+    return enc, grid, min(365, 32 * segments), flat
 
 
 def make_queries(rng, n, TT, extent, nt):
@@ -82,15 +78,15 @@ def make_queries(rng, n, TT, extent, nt):
 
 
 def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_sample=4000, host_results=True, verbose=False):
-    import torch
     import dcdf_amd as dc
     from dcdf_amd import _lib as L, synth
+    from dcdf_amd.encoder import DeviceBuffer
     nt = extent // 256
-    enc, grid, TT = encode_raster(segments, extent)
+    enc, grid, TT, raster = encode_raster(segments, extent)
     t0 = time.perf_counter()
-    chunks = enc.open_chunks()
-    torch.cuda.synchronize()
+    chunks = enc.open_chunks()  # (returns when the device is done: the call synchronises)
     open_s = time.perf_counter() - t0
+    raster.free()  # the queries run against the encoded chunks alone
     # per-instant byte ranges of every chunk (host metadata) -> the touched encoded bytes of a sub-query
     ioff, isnap, base = [], [], [0]
     for c in chunks:
@@ -134,10 +130,10 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
         woff = np.concatenate([[0], np.cumsum(vol)[:-1]]).astype(np.uint64)
         total = int(vol.sum())
         handles = (C.c_void_p * m)(*[chunks[c]._h for c in sub[:, 1]])
-        dev = torch.empty((total,), dtype=torch.int32, device="cuda")
+        dev = DeviceBuffer(max(4, total * 4))
         ms = C.c_float()
         L.check(L.lib().dcdf_query_fill_window_batch_typed(handles, cub.ctypes.data_as(C.POINTER(L.Cube)), C.c_size_t(m),
-                                                           C.c_void_p(dev.data_ptr()), L.DCDF_I32, L.MEM_DEVICE,
+                                                           C.c_void_p(dev.ptr), L.DCDF_I32, L.MEM_DEVICE,
                                                            C.c_void_p(woff.ctypes.data), C.byref(ms)), "fill_window_batch_typed")
         fw_wall += time.perf_counter() - w0
         fw_ms += ms.value
@@ -155,7 +151,7 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
                                                                C.c_void_p(woff.ctypes.data), None), "fill_window_batch_typed")
             fw_wall_host += time.perf_counter() - w0
         if check:
-            out = dev.cpu().numpy()
+            out = dev.read(0, total * 4, np.int32)
             if host_results:
                 assert (out == out_h).all()
             for q in rng.integers(0, half, check):  # reassemble the dataset-level window from its pieces
@@ -171,7 +167,7 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
                 checked += 1
         if len(cpu_f) < cpu_sample:
             cpu_f += [tuple(int(x) for x in sub[k, 1:8]) for k in range(min(m, cpu_sample - len(cpu_f)))]
-        del dev
+        dev.free()
         # ---- search_window half: [lower, upper] = a random 10-percentile-wide band of the value range ----
         w0 = time.perf_counter()
         spec, sub = make_queries(rng, n - half, TT, extent, nt)
@@ -185,9 +181,9 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
         upper = np.ascontiguousarray(qlo[:, 1][sub[:, 0]]).astype(np.int64)
         counts = np.zeros(m, dtype=np.uint64)
         soff = np.zeros(m, dtype=np.uint64)
-        dtrip = torch.empty((total, 3), dtype=torch.int32, device="cuda")
+        dtrip = DeviceBuffer(max(12, total * 12))
         L.check(L.lib().dcdf_query_search_batch_mem(handles, cub.ctypes.data_as(C.POINTER(L.Cube)), C.c_void_p(lower.ctypes.data),
-                                                    C.c_void_p(upper.ctypes.data), C.c_size_t(m), C.c_void_p(dtrip.data_ptr()),
+                                                    C.c_void_p(upper.ctypes.data), C.c_size_t(m), C.c_void_p(dtrip.ptr),
                                                     C.c_size_t(total), L.MEM_DEVICE, C.c_void_p(counts.ctypes.data),
                                                     C.c_void_p(soff.ctypes.data), C.byref(ms)), "search_batch_mem")
         se_wall += time.perf_counter() - w0
@@ -199,7 +195,7 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
         enc_touched_s += int(tb.sum())
         enc_share_s += float((tb * ((sub[:, 5] - sub[:, 4]) * (sub[:, 7] - sub[:, 6])) / 65536.0).sum())
         if check:
-            trip = dtrip.cpu().numpy().astype(np.int64)
+            trip = dtrip.read(0, int(counts.sum()) * 12, np.uint32).reshape(-1, 3).astype(np.int64)
             for q in rng.integers(0, n - half, check):
                 ref, (t0_, r0, c0) = brute(q, spec)
                 want = set(map(tuple, (np.argwhere((ref >= qlo[q, 0]) & (ref <= qlo[q, 1])) + np.array([t0_, r0, c0])).tolist()))
@@ -213,7 +209,7 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
                 checked += 1
         if len(cpu_s) < cpu_sample:
             cpu_s += [tuple(int(x) for x in sub[k, 1:8]) + (int(lower[k]), int(upper[k])) for k in range(min(m, cpu_sample - len(cpu_s)))]
-        del dtrip
+        dtrip.free()
         if verbose:
             print("batch %d done" % b0, file=sys.stderr)
 
