@@ -431,17 +431,36 @@ extern "C" int dcdf_superchunk_build(const dcdf_tile_desc* buffer, const uint32_
     if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
     dcdf_tile_desc dev = *buffer;
     DevBuf stage;
-    if (mem == DCDF_MEM_HOST) {  // dense copy of the whole view in HBM; every tile below is a strided view of it
+    if (mem == DCDF_MEM_HOST) {  // the whole view goes to HBM once; every tile below is a strided view of that copy
         const size_t es = esize(buffer->dtype);
-        const size_t n = (size_t)buffer->instants * buffer->rows * buffer->cols;
-        std::vector<uint8_t> dense(n * es);
-        uint8_t* d = dense.data();
-        for (uint32_t t = 0; t < buffer->instants; t++)
-            for (uint32_t r = 0; r < buffer->rows; r++)
-                for (uint32_t c = 0; c < buffer->cols; c++, d += es)
-                    std::memcpy(d, (const uint8_t*)buffer->base + ((int64_t)t * buffer->stride_t + (int64_t)r * buffer->stride_r + (int64_t)c * buffer->stride_c) * (int64_t)es, es);
-        K2R_HIP(stage.alloc(dense.size()));
-        K2R_HIP(hipMemcpy(stage.p, dense.data(), dense.size(), hipMemcpyHostToDevice));
+        const uint64_t T = buffer->instants, R = buffer->rows, Cc = buffer->cols;
+        const int64_t st = buffer->stride_t, sr = buffer->stride_r, sc = buffer->stride_c;
+        const uint8_t* const base = (const uint8_t*)buffer->base;
+        K2R_HIP(stage.alloc((size_t)(T * R * Cc) * es));
+        if (sc == 1 && sr == (int64_t)Cc && st == (int64_t)(R * Cc)) {
+            // contiguous: one copy straight from the caller's array
+            K2R_HIP(hipMemcpy(stage.p, base, (size_t)(T * R * Cc) * es, hipMemcpyHostToDevice));
+        } else if (sc == 1 && sr >= (int64_t)Cc && st >= 0 && sr >= 0) {
+            // unit column stride (a row-/column-cropped window of a larger array): one 2-D copy per instant, the row pitch does
+            // the gathering -- no dense host copy, no per-element work
+            for (uint64_t t = 0; t < T; t++)
+                K2R_HIP(hipMemcpy2D((uint8_t*)stage.p + (size_t)(t * R * Cc) * es, (size_t)Cc * es, base + (int64_t)t * st * (int64_t)es,
+                                    (size_t)sr * es, (size_t)Cc * es, (size_t)R, hipMemcpyHostToDevice));
+        } else {
+            // general strides (transposed / reversed / stepped views): gathered row by row into one instant's worth of staging
+            std::vector<uint8_t> inst((size_t)(R * Cc) * es);
+            for (uint64_t t = 0; t < T; t++) {
+                uint8_t* d = inst.data();
+                for (uint64_t r = 0; r < R; r++) {
+                    const uint8_t* row = base + ((int64_t)t * st + (int64_t)r * sr) * (int64_t)es;
+                    if (es == 4)
+                        for (uint64_t c = 0; c < Cc; c++, d += 4) *(uint32_t*)d = *(const uint32_t*)(row + (int64_t)c * sc * 4);
+                    else
+                        for (uint64_t c = 0; c < Cc; c++, d += 8) *(uint64_t*)d = *(const uint64_t*)(row + (int64_t)c * sc * 8);
+                }
+                K2R_HIP(hipMemcpy((uint8_t*)stage.p + (size_t)(t * R * Cc) * es, inst.data(), inst.size(), hipMemcpyHostToDevice));
+            }
+        }
         dev.base = stage.p;
         dev.stride_c = 1;
         dev.stride_r = buffer->cols;
