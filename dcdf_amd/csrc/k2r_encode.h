@@ -376,7 +376,7 @@ K2R_HD uint32_t opaque(uint32_t v) {
 // Keeps the instruction scheduler from hoisting the next sub-block's loads above the current sub-block's
 // arithmetic (which would keep 64+ extra cell registers live and spill under the 128-VGPR cap).
 K2R_HD void sched_fence() {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(K2R_NO_SCHED_FENCE)
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
