@@ -547,6 +547,13 @@ typedef WaveQ2T<int64_t> WaveQ2;
 // no two waves share a word, so there is nothing atomic about it and nothing to clear beforehand).
 struct SearchExtra {
     int64_t lower, upper;
+    // The reference's Log::search_window has no case for a single-node UNIFORM log over a multi-node snapshot (log.rs:527-548):
+    // it never reads eqB[0], seeds min_t with an empty Dac's 0 and descends the snapshot as if the log were "equal" with the
+    // root's difference.  Read as data, its result for such an instant is: every cell when min_s(root) >= lower and c <= upper
+    // (c = the instant's one value), no cell when min_s(root) > upper or c < lower, and otherwise the cells with
+    // lower <= s(cell) + (c - max_s(root)) <= upper.  quirk != 0 makes the walk do exactly that instead of the decode of the
+    // instant's true values.
+    uint32_t quirk, _pad;
 };
 // MW = waves per SIMD the register allocator must leave room for (4 for the 32-bit walk; the 64-bit one's frontier leaves LDS
 // for 3 workgroups per CU, so it is built for 3); DENSE64: the batched form's output (int64, unit column stride);
@@ -578,9 +585,11 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
         const uint32_t wtop = I.top, wbot = I.bottom, wleft = I.left, wright = I.right, osr = I.out_sr;
         const int64_t obase = (int64_t)I.out_off - (int64_t)wtop * osr - (int64_t)wleft;  // element offset of chunk cell (0, 0)
         int64_t s_lo = 0, s_hi = 0;
+        bool quirk = false;
         if (SEARCH) {
             s_lo = sx[item].lower;
             s_hi = sx[item].upper;
+            quirk = __builtin_amdgcn_readfirstlane((int)sx[item].quirk) != 0;
             rowbits[2 * lane] = 0;
             rowbits[2 * lane + 1] = 0;
             __builtin_amdgcn_wave_barrier();
@@ -625,7 +634,7 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
             }
         };
         uint32_t lo = 0, hi = 1, side = sidelen0;
-        if (USE_TOP && C.top) {  // start at the (up to 5 x 5) nodes of side 16 that meet the item (k_top_table)
+        if (USE_TOP && C.top && !(SEARCH && quirk)) {  // start at the (up to 5 x 5) nodes of side 16 that meet the item (k_top_table)
             typedef __attribute__((address_space(1))) const TopEnt* gtop;
             const uint32_t r16 = wtop >> 4, c16 = wleft >> 4, nr16 = ((wbot - 1u) >> 4) - r16 + 1u, nc16 = ((wright - 1u) >> 4) - c16 + 1u;  // <= 5 each
             const uint32_t qi = (uint32_t)lane / nc16, qj = (uint32_t)lane - qi * nc16;
@@ -684,7 +693,19 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
             const bool single_t = has_log ? !gbm_get(gb, L.T, 0) : true;
             const int64_t max_s0 = dacd_get(b, SD.mx, 0), max_t0 = has_log ? dacd_get(b, D.mx, 0) : 0;
             const bool all_one = has_log ? (single_t && (single_s || !gbm_get(gb, L.E, 0))) : single_s;
-            if (all_one) {
+            if (SEARCH && quirk) {  // (see SearchExtra: the reference's result for this shape, log.rs:527-586)
+                const int64_t min_s0 = dacd_get(b, SD.mn, 0), c1 = max_t0 + max_s0;
+                if (min_s0 >= s_lo && c1 <= s_hi) {
+                    fill_wave(wtop, wbot, wleft, wright, s_lo);  // every cell
+                    flush_bits();
+                    continue;
+                }
+                if (min_s0 > s_hi || c1 < s_lo) {
+                    flush_bits();
+                    continue;
+                }
+                // else: the snapshot's tree with the root's difference on top of every value (the walk below, it = NONE)
+            } else if (all_one) {
                 fill_wave(wtop, wbot, wleft, wright, max_t0 + max_s0);
                 flush_bits();
                 continue;
@@ -1718,7 +1739,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         if (cells == 0) continue;
         const uint32_t ncb = (c.right - c.left + 63u) >> 6;
         for (uint32_t i = c.start; i < c.end; i++) {
-            if (node_wise && !chunks[q]->search_quirk[i]) {
+            if (node_wise) {
                 if (witems.size() + 4096 > 0xffffff00u) return DCDF_ERR_CAPACITY;
                 items.push_back(SearchItem{(uint32_t)q, i, 0, (uint32_t)witems.size(), ncb});
                 for (uint32_t r = c.top; r < c.bottom; r += 64)
@@ -1731,7 +1752,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
                         it.left = (uint16_t)cc;
                         it.right = (uint16_t)std::min(cc + 64, c.right);
                         witems.push_back(it);
-                        sx.push_back(SearchExtra{Q.lower, Q.upper});
+                        sx.push_back(SearchExtra{Q.lower, Q.upper, chunks[q]->search_quirk[i] ? 1u : 0u, 0u});
                     }
             } else {
                 items.push_back(SearchItem{(uint32_t)q, i, bits_words, SI_FLAT, 0});

@@ -143,6 +143,16 @@ def test_log_search_reference_quirk_reproduced(dc):
             for hi in range(lo, 24, 3):
                 got = set(map(tuple, c.iter_search(dc.Cube(1, 2, 1, 7, 2, 8), lo, hi).tolist()))
                 assert got == set(map(tuple, oc.search(1, 2, 1, 7, 2, 8, lo, hi).tolist()))
+    # the same shape on a tile that HAS side-16 tables (sidelen 64): the quirk instant must bypass them, the others use them
+    rng = np.random.default_rng(64)
+    s64 = rng.integers(0, 40, size=(64, 64)).astype(np.int64)
+    for tv in (55, 17, -3):
+        data = O.chunk_build_forced(np.stack([s64, np.zeros((64, 64), dtype=np.int64) + tv, s64 + 1]), 2, 3)
+        c, oc = dc.Chunk(data), O.Chunk(data)
+        for lo, hi in [(-10, 100), (0, 39), (10, 20), (tv, tv), (tv - 5, tv + 5), (40, 60), (-8, -1), (16, 18), (39, 56)]:
+            for cube in [(0, 3, 0, 64, 0, 64), (1, 2, 5, 40, 17, 64), (1, 3, 30, 34, 0, 7)]:
+                got = set(map(tuple, c.iter_search(dc.Cube(*cube), lo, hi).tolist()))
+                assert got == set(map(tuple, oc.search(*cube, lo, hi).tolist())), (tv, lo, hi, cube)
 
 
 def test_synthetic_256_roundtrip_and_batches(dc):
