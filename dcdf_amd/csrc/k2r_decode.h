@@ -5,8 +5,8 @@
 // Snapshot::get/_search_window (snapshot.rs:165-188, 347-421), Log::get/_search_window
 // (log.rs:176-293, 553-702).  The host parses the layout once (chunk.rs:247-266 et al.) into
 // InstDesc records holding byte offsets; kernels then index the raw big-endian stream directly.
-// Search reproduces the reference's pruning decisions exactly (including snapshot.rs:392 and the
-// root handling of single-node logs, log.rs:527-548) so the result SET is the reference's.
+// Search is not in this header: its result SET is the reference's because decoding is exact and the one shape where the
+// reference's own search is not "the cells in range" (log.rs:527-548) is carried as data (k2r_query.hip, SearchExtra).
 #pragma once
 #include "k2r_common.h"
 
@@ -147,168 +147,6 @@ K2R_HD void store_typed(void* out, int64_t off, int32_t dtype, int64_t v, uint32
             break;
         }
     }
-}
-
-// ---- search (faithful DFS with the reference's pruning) ---------------------------------------------
-// Results are marked in a bitmap over the window (bit = (row-top)*wcols + (col-left)), owned by one thread.
-struct WinMark {
-    uint32_t* bits;
-    uint32_t top, left, wcols;
-    K2R_HD void rect(uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1) const {  // inclusive bounds
-        for (uint32_t r = r0; r <= r1; r++) {
-            const uint32_t base = (r - top) * wcols - left;
-            for (uint32_t c = c0; c <= c1; c++) {
-                const uint32_t p = base + c;
-                bits[p >> 5] |= 1u << (p & 31);
-            }
-        }
-    }
-};
-
-constexpr int MAX_DEPTH = 20;
-
-struct SFrame {  // one activation of _search_window
-    uint32_t sl, base_t, base_s;  // child side length, first-child index in log / snapshot tree
-    uint32_t top, bottom, left, right, toff, loff;
-    uint32_t i, j, i_end, j0, j_end;
-    int64_t min_t, min_s, max_t, max_s;
-    uint8_t has_t, has_s;
-};
-
-// Snapshot::search_window, snapshot.rs:310-421
-K2R_HD void snapshot_search(const uint8_t* b, const InstDesc& S, uint32_t top, uint32_t bottom, uint32_t left,
-                            uint32_t right, int64_t lower, int64_t upper, const WinMark& wm) {
-    // bounds are half-open on entry (geom::Rect); the recursion uses inclusive ones (snapshot.rs:329-332)
-    if (!bmd_get(b, S.T, 0)) {
-        const int64_t v = dacd_get(b, S.mx, 0);
-        if (lower <= v && v <= upper) wm.rect(top, bottom - 1, left, right - 1);
-        return;
-    }
-    const uint32_t k = S.k;
-    SFrame st[MAX_DEPTH];
-    int sp = 0;
-    auto enter = [&](uint32_t sidelen, uint32_t t, uint32_t bo, uint32_t l, uint32_t r, uint32_t index, int64_t mn,
-                     int64_t mx, uint32_t toff, uint32_t loff) {
-        if (sidelen / k == 0) return;  // (malformed input only: dcdf_chunk_open rejects a sidelen that is no power of k)
-        SFrame& f = st[sp++];
-        f.sl = sidelen / k;
-        f.base_s = 1 + bmd_rank(b, S.T, index) * k * k;
-        f.top = t; f.bottom = bo; f.left = l; f.right = r; f.toff = toff; f.loff = loff;
-        f.i = t / f.sl; f.i_end = bo / f.sl; f.j0 = l / f.sl; f.j_end = r / f.sl; f.j = f.j0;
-        f.min_s = mn; f.max_s = mx;
-    };
-    enter(S.sidelen, top, bottom - 1, left, right - 1, 0, dacd_get(b, S.mn, 0), dacd_get(b, S.mx, 0), 0, 0);
-    while (sp > 0) {
-        SFrame& f = st[sp - 1];
-        if (f.i > f.i_end) {
-            sp--;
-            continue;
-        }
-        const uint32_t i = f.i, j = f.j;
-        if (++f.j > f.j_end) {
-            f.j = f.j0;
-            f.i++;
-        }
-        const uint32_t sl = f.sl;
-        const uint32_t top_ = f.top > i * sl ? f.top - i * sl : 0;
-        const uint32_t bottom_ = (f.bottom - i * sl) < (sl - 1) ? (f.bottom - i * sl) : (sl - 1);
-        const uint32_t toff_ = f.toff + i * sl;
-        const uint32_t left_ = f.left > j * sl ? f.left - j * sl : 0;
-        const uint32_t right_ = (f.right - j * sl) < (sl - 1) ? (f.right - j * sl) : (sl - 1);
-        const uint32_t loff_ = f.loff + j * sl;
-        const uint32_t index_ = f.base_s + i * k + j;
-        const int64_t max_value_ = f.max_s - dacd_get(b, S.mx, index_);
-        if (index_ >= S.T.len || !bmd_get(b, S.T, index_)) {
-            if (lower <= max_value_ && max_value_ <= upper) wm.rect(toff_ + top_, toff_ + bottom_, loff_ + left_, loff_ + right_);
-        } else {
-            const int64_t min_value_ = f.min_s + dacd_get(b, S.mn, bmd_rank(b, S.T, index_));
-            if (lower <= f.min_s && max_value_ <= upper) {  // sic: the PARENT's min (snapshot.rs:392)
-                wm.rect(toff_ + top_, toff_ + bottom_, loff_ + left_, loff_ + right_);
-            } else if (upper >= min_value_ && lower <= max_value_) {
-                if (sp < MAX_DEPTH && sl > 1) enter(sl, top_, bottom_, left_, right_, index_, min_value_, max_value_, toff_, loff_);
-            }
-        }
-    }
-}
-
-// Log::search_window, log.rs:519-702
-K2R_HD void log_search(const uint8_t* b, const InstDesc& S, const InstDesc& L, uint32_t top, uint32_t bottom,
-                       uint32_t left, uint32_t right, int64_t lower, int64_t upper, const WinMark& wm) {
-    const uint32_t k = L.k;
-    const bool single_t = !bmd_get(b, L.T, 0);
-    const bool single_s = !bmd_get(b, S.T, 0);
-    SFrame st[MAX_DEPTH];
-    int sp = 0;
-    // returns true when the activation recursed (a frame was pushed)
-    auto call = [&](uint32_t sidelen, uint32_t t, uint32_t bo, uint32_t l, uint32_t r, bool has_t, uint32_t index_t,
-                    bool has_s, uint32_t index_s, int64_t min_t, int64_t min_s, int64_t max_t, int64_t max_s,
-                    uint32_t toff, uint32_t loff) {
-        const int64_t max_value = max_s + max_t, min_value = min_s + min_t;  // log.rs:573-574
-        if (min_value >= lower && max_value <= upper) {
-            wm.rect(toff + t, toff + bo, loff + l, loff + r);
-            return;
-        }
-        if (min_value > upper || max_value < lower) return;
-        const uint32_t sl = sidelen / k;
-        if (sl == 0 || sp >= MAX_DEPTH) return;
-        SFrame& f = st[sp++];
-        f.sl = sl;
-        f.has_t = has_t; f.has_s = has_s;
-        f.base_t = has_t ? 1 + bmd_rank(b, L.T, index_t) * k * k : 0;
-        f.base_s = has_s ? 1 + bmd_rank(b, S.T, index_s) * k * k : 0;
-        f.top = t; f.bottom = bo; f.left = l; f.right = r; f.toff = toff; f.loff = loff;
-        f.i = t / sl; f.i_end = bo / sl; f.j0 = l / sl; f.j_end = r / sl; f.j = f.j0;
-        f.min_t = min_t; f.min_s = min_s; f.max_t = max_t; f.max_s = max_s;
-    };
-    call(L.sidelen, top, bottom - 1, left, right - 1, !single_t, 0, !single_s, 0, dacd_get(b, L.mn, 0),
-         dacd_get(b, S.mn, 0), dacd_get(b, L.mx, 0), dacd_get(b, S.mx, 0), 0, 0);
-    while (sp > 0) {
-        SFrame& f = st[sp - 1];
-        if (f.i > f.i_end) {
-            sp--;
-            continue;
-        }
-        const uint32_t i = f.i, j = f.j;
-        if (++f.j > f.j_end) {
-            f.j = f.j0;
-            f.i++;
-        }
-        const uint32_t sl = f.sl;
-        const uint32_t top_ = f.top > i * sl ? f.top - i * sl : 0;
-        const uint32_t bottom_ = (f.bottom - i * sl) < (sl - 1) ? (f.bottom - i * sl) : (sl - 1);
-        const uint32_t toff_ = f.toff + i * sl;
-        const uint32_t left_ = f.left > j * sl ? f.left - j * sl : 0;
-        const uint32_t right_ = (f.right - j * sl) < (sl - 1) ? (f.right - j * sl) : (sl - 1);
-        const uint32_t loff_ = f.loff + j * sl;
-        bool has_t = f.has_t, has_s = f.has_s;
-        const uint32_t it = f.base_t + i * k + j, is = f.base_s + i * k + j;
-        const int64_t max_t_ = has_t ? dacd_get(b, L.mx, it) : f.max_t;                 // log.rs:622-625
-        const int64_t max_s_ = has_s ? f.max_s - dacd_get(b, S.mx, is) : f.max_s;       // log.rs:627-630
-        const bool leaf_t = has_t ? (it >= L.T.len || !bmd_get(b, L.T, it)) : true;     // log.rs:632-635
-        const bool leaf_s = has_s ? (is >= S.T.len || !bmd_get(b, S.T, is)) : true;
-        int64_t min_t_ = has_t ? (leaf_t ? f.min_t : dacd_get(b, L.mn, bmd_rank(b, L.T, it))) : f.min_t;
-        int64_t min_s_ = has_s ? (leaf_s ? f.min_s : f.min_s + dacd_get(b, S.mn, bmd_rank(b, S.T, is))) : f.min_s;
-        if (leaf_s) {
-            min_s_ = max_s_;
-            has_s = false;
-        }
-        if (leaf_t) {
-            min_t_ = max_t_;
-            if (has_t) {
-                if (it < L.T.len && !bmd_get(b, L.E, bmd_rank0(b, L.T, it + 1) - 1)) min_t_ = max_s_ + max_t_ - min_s_;
-            }
-            has_t = false;
-        }
-        // copy what the callee needs before `call` may push a frame that aliases nothing of f
-        call(sl, top_, bottom_, left_, right_, has_t, it, has_s, is, min_t_, min_s_, max_t_, max_s_, toff_, loff_);
-    }
-}
-
-K2R_HD void inst_search(const uint8_t* b, const InstDesc* descs, uint32_t i, uint32_t top, uint32_t bottom,
-                        uint32_t left, uint32_t right, int64_t lower, int64_t upper, const WinMark& wm) {
-    const InstDesc& D = descs[i];
-    if (!D.is_log) snapshot_search(b, D, top, bottom, left, right, lower, upper, wm);  // block.rs:70-81
-    else log_search(b, descs[D.snap], D, top, bottom, left, right, lower, upper, wm);
 }
 
 }  // namespace k2r

@@ -994,7 +994,7 @@ k_search_count(const uint32_t* __restrict__ wbits, const SearchItem* __restrict_
     const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= n) return;
     const SearchItem I = items[it];
-    if (I.w0 == SI_FLAT) return;  // (counted by k_search_mark)
+    if (I.w0 == SI_FLAT) return;  // (counted by k_search_cells)
     const WinQuery Q = qs[I.query];
     const uint32_t nrb = (Q.bottom - Q.top + 63u) >> 6;
     const uint4* w = (const uint4*)(wbits + (uint64_t)I.w0 * 128u);
@@ -1049,23 +1049,53 @@ __global__ void __launch_bounds__(256) k_slab_pack(const SlabItem* __restrict__ 
     }
 }
 
-// search pass 1: one thread per (query, instant) item runs the reference's pruned DFS and marks matches
-// in its private window bitmap.
+// search pass 1 for chunks the wave walk does not take (k != 2): decode and test.  One WAVE per (query, instant) item; the
+// lanes stride over the window's cells, each a root-to-leaf descent (inst_get), and mark the cells in range in the item's flat
+// window bitmap.  The reference's search is a pruned descent whose result is exactly that set (its bounds are true bounds) --
+// except for the single-node-uniform-log shape of SearchExtra, which is evaluated here as the data it is: all cells, no cell, or
+// the cells with lower <= s(cell) + (c - max_s(root)) <= upper.
 __global__ void __launch_bounds__(64)
-k_search_mark(const ChunkRef* __restrict__ chunks, const WinQuery* __restrict__ qs, const SearchItem* __restrict__ items,
-              uint32_t n_items, uint32_t* __restrict__ bits, uint32_t* __restrict__ counts) {
-    const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+k_search_cells(const ChunkRef* __restrict__ chunks, const WinQuery* __restrict__ qs, const SearchItem* __restrict__ items,
+               uint32_t n_items, const uint8_t* __restrict__ quirk, uint32_t* __restrict__ bits, uint32_t* __restrict__ counts) {
+    const uint32_t it = blockIdx.x;
     if (it >= n_items) return;
     const SearchItem I = items[it];
     if (I.w0 != SI_FLAT) return;  // (marked by the wave walk)
+    const int lane = threadIdx.x;
     const WinQuery Q = qs[I.query];
     const ChunkRef C = chunks[Q.chunk];
-    WinMark wm{bits + I.bits_off, Q.top, Q.left, Q.right - Q.left};
-    inst_search(C.bytes, C.descs, I.instant, Q.top, Q.bottom, Q.left, Q.right, Q.lower, Q.upper, wm);
-    const uint32_t nbits = (Q.bottom - Q.top) * (Q.right - Q.left);
+    const uint8_t* const b = C.bytes;
+    const uint32_t wc = Q.right - Q.left, ncell = (Q.bottom - Q.top) * wc;
+    uint32_t* const bw = bits + I.bits_off;
+    const InstDesc& D = C.descs[I.instant];
+    bool all = false, none = false;
+    int64_t shift = 0;
+    uint32_t from = I.instant;
+    if (quirk[it]) {  // (log.rs:527-586 on this shape)
+        const InstDesc& S = C.descs[D.snap];
+        const int64_t max_s0 = dacd_get(b, S.mx, 0), min_s0 = dacd_get(b, S.mn, 0), c1 = dacd_get(b, D.mx, 0) + max_s0;
+        all = min_s0 >= Q.lower && c1 <= Q.upper;
+        none = !all && (min_s0 > Q.upper || c1 < Q.lower);
+        shift = c1 - max_s0;
+        from = D.snap;
+    }
     uint32_t cnt = 0;
-    for (uint32_t w = 0; w < (nbits + 31) / 32; w++) cnt += popc32(wm.bits[w]);
-    counts[it] = cnt;
+    if (!none) {
+        for (uint32_t e = (uint32_t)lane; e < ncell; e += 64) {
+            bool hit = all;
+            if (!all) {
+                const int64_t v = inst_get(b, C.descs, from, Q.top + e / wc, Q.left + e % wc) + shift;
+                hit = Q.lower <= v && v <= Q.upper;
+            }
+            if (hit) {
+                atomicOr(&bw[e >> 5], 1u << (e & 31u));
+                cnt++;
+            }
+        }
+    }
+    // wave total (DPP-free: a shuffle ladder is fine here)
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if (lane == 0) counts[it] = cnt;
 }
 // search pass 2: expand the bitmaps into sorted (instant,row,col) triples
 __global__ void __launch_bounds__(64)
@@ -1717,12 +1747,13 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     std::vector<WinQuery> qs(nq);
     std::vector<SearchItem> items;
     // k = 2 chunks: the wave-cooperative walk of fill_window marks the matches (one wave per piece of <= 64 x 64 cells and
-    // instant, each into its own 128-word bitmap); other arities -- and the instants of dcdf_chunk::search_quirk -- keep the
-    // per-thread pruned descent and its flat per-item bitmap
-    bool node_wise = std::getenv("K2R_SEARCH_DFS") == nullptr;  // (diagnostics: A/B against the per-thread descent)
+    // instant, each into its own 128-word bitmap; the instants of dcdf_chunk::search_quirk carry a flag); other arities are
+    // decoded and tested cell by cell (k_search_cells) into a flat per-item bitmap
+    bool node_wise = std::getenv("K2R_SEARCH_DFS") == nullptr;  // (diagnostics: A/B against the cell-by-cell kernel)
     for (const dcdf_chunk* u : uniq) node_wise = node_wise && node_kernel_ok(u);
     std::vector<WinItem> witems;
     std::vector<SearchExtra> sx;
+    std::vector<uint8_t> item_quirk;  // per item of the decode-and-test kernel
     uint64_t bits_words = 0;
     size_t n_dfs = 0;
     for (size_t q = 0; q < nq; q++) {
@@ -1756,6 +1787,8 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
                     }
             } else {
                 items.push_back(SearchItem{(uint32_t)q, i, bits_words, SI_FLAT, 0});
+                item_quirk.resize(items.size(), 0);
+                item_quirk.back() = chunks[q]->search_quirk[i];
                 bits_words += (cells + 31) / 32;
                 n_dfs++;
             }
@@ -1764,7 +1797,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     for (size_t q = 0; q < nq; q++) counts[q] = 0;
     float ms_total = 0.f;
     std::vector<uint32_t> item_counts(items.size());
-    DevBuf d_refs, d_qs, d_items, d_bits, d_wbits, d_witems, d_sx, d_counts, d_offs, d_out;
+    DevBuf d_refs, d_qs, d_items, d_bits, d_wbits, d_witems, d_sx, d_counts, d_offs, d_out, d_quirk;
     if (!items.empty()) {
         int rc = upload_refs(chunks, cidx, uniq.size(), uniq, d_refs);
         if (rc != DCDF_OK) return rc;
@@ -1802,9 +1835,13 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
             hipLaunchKernelGGL(k_search_count, dim3((ni + 63) / 64), dim3(64), 0, 0, d_wbits.as<uint32_t>(), d_items.as<SearchItem>(),
                                d_qs.as<WinQuery>(), ni, d_counts.as<uint32_t>());
         }
-        if (n_dfs)
-            hipLaunchKernelGGL(k_search_mark, dim3((ni + 63) / 64), dim3(64), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
-                               d_items.as<SearchItem>(), ni, d_bits.as<uint32_t>(), d_counts.as<uint32_t>());
+        if (n_dfs) {
+            item_quirk.resize(items.size(), 0);
+            K2R_HIP(d_quirk.alloc(items.size()));
+            K2R_HIP(hipMemcpy(d_quirk.p, item_quirk.data(), items.size(), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_search_cells, dim3(ni), dim3(64), 0, 0, d_refs.as<ChunkRef>(), d_qs.as<WinQuery>(),
+                               d_items.as<SearchItem>(), ni, d_quirk.as<uint8_t>(), d_bits.as<uint32_t>(), d_counts.as<uint32_t>());
+        }
         K2R_HIP(hipEventRecord(e1, 0));
         K2R_HIP(hipGetLastError());
         K2R_HIP(hipMemcpy(item_counts.data(), d_counts.p, items.size() * 4, hipMemcpyDeviceToHost));

@@ -59,10 +59,10 @@ def audit_kernels(obj):
 # the other kernels of the library (query, universal encoder, superchunk assembly, hashing, float ingestion): the same
 # failure mode -- LDS state behind a pointer the compiler lost track of, reached through FLAT instructions, a 12/16-byte
 # one of which faults when it lands in LDS at 4-byte alignment -- is excluded per kernel: a kernel with LDS state must reach
-# it with ds_ instructions, and must not keep more than spill-sized scratch (the per-thread descent stacks of the search
-# fallback are the one sanctioned exception, MAX_SCRATCH_OTHER).
+# it with ds_ instructions, and must not keep more than MAX_SCRATCH_OTHER bytes of scratch per lane (the universal encoder's
+# per-thread level cursors are the largest today, 560 B).
 OTHER_OBJECTS = ["k2r_query.o", "k2r_generic.o", "k2r_superchunk.o", "k2r_cid.o", "k2r_suggest.o", "k2r_synth.o"]
-MAX_SCRATCH_OTHER = 2048
+MAX_SCRATCH_OTHER = 1024
 
 
 def main():
