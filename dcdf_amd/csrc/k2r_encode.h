@@ -785,14 +785,18 @@ struct EmTag {
 // global-memory byte store (the pointers travel through structs, so the compiler would otherwise have to
 // emit flat_store_byte)
 K2R_HD void gstore8(uint8_t* p, uint8_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(K2R_EXP_NOSTORE)
+    asm volatile("" ::"v"(p), "v"((uint32_t)v));  // experiment: the address and the value are computed, nothing is stored
+#elif defined(__HIP_DEVICE_COMPILE__)
     *(__attribute__((address_space(1))) uint8_t*)p = v;
 #else
     *p = v;
 #endif
 }
 K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(K2R_EXP_NOSTORE)
+    asm volatile("" ::"v"(p), "v"(v));
+#elif defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
     *(__attribute__((address_space(1))) u32_unaligned*)p = v;
 #else
