@@ -785,18 +785,14 @@ struct EmTag {
 // global-memory byte store (the pointers travel through structs, so the compiler would otherwise have to
 // emit flat_store_byte)
 K2R_HD void gstore8(uint8_t* p, uint8_t v) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(K2R_EXP_NOSTORE)
-    asm volatile("" ::"v"(p), "v"((uint32_t)v));  // experiment: the address and the value are computed, nothing is stored
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     *(__attribute__((address_space(1))) uint8_t*)p = v;
 #else
     *p = v;
 #endif
 }
 K2R_HD void gstore32u(uint8_t* p, uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(K2R_EXP_NOSTORE)
-    asm volatile("" ::"v"(p), "v"(v));
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
     *(__attribute__((address_space(1))) u32_unaligned*)p = v;
 #else
@@ -1067,24 +1063,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             auto lng = [](int32_t v) -> uint32_t { return ((uint32_t)v + 128u) > 255u ? 1u : 0u; };  // zig-zag(v) > 0xff
             int32_t df2_0 = 0, mn3 = 0, mx3 = 0, smn3 = 0, smx3 = 0;
             uint32_t eqbits = 0, eqall = 1, cntbits = 0, wide = 0, u2 = 0;
-#if defined(K2R_EXP_PAD) && defined(__HIP_DEVICE_COMPILE__)
-            // issue-model experiment: a block of dummy VALU (1) or SALU (2) instructions per sub-block
-            uint32_t padv = (uint32_t)tid, pads = inst;
-#endif
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 sched_fence();
-#if defined(K2R_EXP_PAD) && defined(__HIP_DEVICE_COMPILE__)
-#if K2R_EXP_PAD == 1
-#pragma unroll
-                for (int z = 0; z < K2R_EXP_N; z++) asm volatile("v_add_u32 %0, %0, %0" : "+v"(padv));
-#elif K2R_EXP_PAD == 2
-#pragma unroll
-                for (int z = 0; z < K2R_EXP_N; z++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pads) : : "scc");
-#endif
-                asm volatile("" : "+v"(padv), "+s"(pads));
-                sched_fence();
-#endif
                 const uint32_t rj = r0 + 4 * (j >> 1), cj = c0 + 4 * (j & 1);
                 const bool inv2 = inval(rj, cj);
                 int32_t t16[16];

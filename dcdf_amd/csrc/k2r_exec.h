@@ -183,11 +183,7 @@ struct GpuExec {
 
 
     __device__ __forceinline__ uint32_t lds_or_nr(uint32_t* p, uint32_t v) { atomicOr(p, v); return 0; }
-#ifdef K2R_EXP_NOBM
-    __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { asm volatile("" ::"v"(p), "v"(v)); return 0; }  // experiment
-#else
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
-#endif
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
     __device__ __forceinline__ int32_t lds_min(int32_t* p, int32_t v) { return atomicMin(p, v); }
 
