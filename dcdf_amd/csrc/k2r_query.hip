@@ -1389,7 +1389,13 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
             continue;
         }
         std::unique_ptr<dcdf_chunk> c(new (std::nothrow) dcdf_chunk());
-        if (!c) return DCDF_ERR_NOMEM;
+        if (!c) {
+            for (size_t j = 0; j < i; j++) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            return DCDF_ERR_NOMEM;
+        }
         c->descs.assign(descs.begin() + first[i], descs.begin() + first[i + 1]);
         c->instants = meta[i].n_inst;
         c->rows = meta[i].rows;
@@ -1477,9 +1483,8 @@ struct PinnedPage {
         out = (int64_t*)((uint8_t*)base + 256 + kPoints * sizeof(PointQuery));
         return true;
     }
-    ~PinnedPage() {
-        if (base) (void)hipHostFree(base);
-    }
+    // (never freed: a thread_local destructor of the main thread would run after the HIP runtime has shut down; one page per
+    // host thread that ever asked a single point lives as long as the process)
 };
 thread_local PinnedPage g_page;
 }  // namespace
