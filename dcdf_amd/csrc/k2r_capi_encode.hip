@@ -683,16 +683,25 @@ extern "C" int dcdf_encoder_gather(dcdf_encoder* e, uint8_t* dst, size_t cap, ui
     }
     if (tot > cap) return DCDF_ERR_CAPACITY;
     if (!items.empty()) {
+        // on a stream of its own: the gather only reads what a finished run left behind, so it may overlap other readers of the
+        // session (the superchunk assembly hashes the objects on the session's stream meanwhile)
+        struct OwnStream {
+            hipStream_t s = nullptr;
+            ~OwnStream() {
+                if (s) (void)hipStreamDestroy(s);
+            }
+        } own;
+        K2R_HIP(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
         DevBuf d_items, d_packed;
         K2R_HIP(d_items.alloc(items.size() * sizeof(PackItem)));
         K2R_HIP(d_packed.alloc(tot));
-        K2R_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice, e->stream));
+        K2R_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice, own.s));
         const uint32_t grid = (uint32_t)std::min<size_t>(items.size(), 8192);
-        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, e->stream, d_items.as<PackItem>(), (uint32_t)items.size(),
+        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, own.s, d_items.as<PackItem>(), (uint32_t)items.size(),
                            d_packed.as<uint8_t>());
         K2R_HIP(hipGetLastError());
-        K2R_HIP(hipMemcpyAsync(dst, d_packed.p, tot, hipMemcpyDeviceToHost, e->stream));
-        K2R_HIP(hipStreamSynchronize(e->stream));
+        K2R_HIP(hipMemcpyAsync(dst, d_packed.p, tot, hipMemcpyDeviceToHost, own.s));
+        K2R_HIP(hipStreamSynchronize(own.s));
     }
     if (minmax && e->minmax_total) K2R_HIP(hipMemcpy(minmax, e->d_minmax.p, e->minmax_total * 8, hipMemcpyDeviceToHost));
     return DCDF_OK;

@@ -38,14 +38,20 @@ __device__ __forceinline__ F sf_load(const SfView& v, uint64_t i) {
     return ((const F*)v.base)[(int64_t)t * v.st + (int64_t)r * v.sr + (int64_t)c * v.sc];
 }
 
+// Workgroup b looks at view b / bpt (bpt workgroups per view stride over its cells); maxbits[view] = pass 2's widest shift.
+// One launch per pass covers every float tile of a superchunk level (dcdf_suggest_fraction: a batch of one).
 template <class F, int PASS>
-__global__ void __launch_bounds__(256) k_suggest(SfView v, uint64_t n, uint32_t max_fraction_bits, SfPartial* out) {
+__global__ void __launch_bounds__(256) k_suggest(const SfView* __restrict__ views, const uint32_t* __restrict__ maxbits, uint32_t bpt,
+                                                 SfPartial* out) {
     __shared__ double s_max[4];
     __shared__ uint32_t s_a[4], s_b[4];
+    const SfView v = views[blockIdx.x / bpt];
+    const uint64_t n = (uint64_t)v.instants * v.rows * v.cols;
+    const uint32_t max_fraction_bits = PASS == 2 ? maxbits[blockIdx.x / bpt] : 0u;
     double mx = 0.0;
     uint32_t seen = 0, bits = 0, frac = 0;
     const double scale = (double)((int64_t)1 << max_fraction_bits);
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    for (uint64_t i = (uint64_t)(blockIdx.x % bpt) * 256 + threadIdx.x; i < n; i += (uint64_t)bpt * 256) {
         const double x = (double)sf_load<F>(v, i);
         if (x != x) continue;  // NaN: skipped by both loops (fixed.rs:108-123,140-142)
         if (PASS == 1) {
@@ -101,6 +107,79 @@ __global__ void __launch_bounds__(256) k_suggest(SfView v, uint64_t n, uint32_t 
 
 using namespace k2r;
 
+namespace k2r {
+// suggest_fraction (fixed.rs:96-159) for n float tiles in DEVICE memory, two launches in all: (round, bits, status) per tile.
+int suggest_fraction_batch(const dcdf_tile_desc* tiles, size_t n, int32_t* out_round, int32_t* out_bits, int32_t* status) {
+    Runtime& rt = Runtime::get();
+    if (!rt.ok) return DCDF_ERR_NO_DEVICE;
+    if (n == 0) return DCDF_OK;
+    const int dtype = tiles[0].dtype;
+    std::vector<SfView> views(n);
+    uint64_t most = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (tiles[i].dtype != dtype) return DCDF_ERR_BAD_ARG;
+        views[i] = SfView{tiles[i].base, tiles[i].stride_t, tiles[i].stride_r, tiles[i].stride_c, tiles[i].instants, tiles[i].rows, tiles[i].cols};
+        most = std::max<uint64_t>(most, (uint64_t)tiles[i].instants * tiles[i].rows * tiles[i].cols);
+        status[i] = DCDF_OK;
+    }
+    // workgroups per tile: enough to fill the card across the batch, no more than the largest tile has 256-cell pieces
+    const uint32_t bpt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((most + 255) / 256, ((uint64_t)rt.cus * 8 + n - 1) / n));
+    const uint32_t grid = (uint32_t)(n * bpt);
+    DevBuf d_views, d_bits, d_part;
+    K2R_HIP(d_views.alloc(n * sizeof(SfView)));
+    K2R_HIP(hipMemcpy(d_views.p, views.data(), n * sizeof(SfView), hipMemcpyHostToDevice));
+    K2R_HIP(d_bits.alloc(n * 4));
+    K2R_HIP(d_part.alloc((size_t)grid * sizeof(SfPartial)));
+    std::vector<SfPartial> part(grid);
+    if (dtype == DCDF_F32) hipLaunchKernelGGL((k_suggest<float, 1>), dim3(grid), dim3(256), 0, 0, d_views.as<SfView>(), d_bits.as<uint32_t>(), bpt, d_part.as<SfPartial>());
+    else hipLaunchKernelGGL((k_suggest<double, 1>), dim3(grid), dim3(256), 0, 0, d_views.as<SfView>(), d_bits.as<uint32_t>(), bpt, d_part.as<SfPartial>());
+    K2R_HIP(hipGetLastError());
+    K2R_HIP(hipMemcpy(part.data(), d_part.p, (size_t)grid * sizeof(SfPartial), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> maxbits(n, 0);
+    std::vector<char> all_nan(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        bool seen = false;
+        double mx = 0.0;
+        for (uint32_t b = 0; b < bpt; b++) {
+            const SfPartial& p = part[i * bpt + b];
+            if (p.seen) {
+                mx = seen ? std::max(mx, p.max) : p.max;
+                seen = true;
+            }
+        }
+        if (!seen) {  // all NaN (fixed.rs:124-127)
+            all_nan[i] = 1;
+            continue;
+        }
+        // whole_bits = 1 + log2(max).floor() as usize  (saturating float->usize cast: negative / NaN -> 0), fixed.rs:129
+        const double lg = std::floor(std::log2(mx));
+        if (lg > 61.0) {  // TOTAL_BITS - whole_bits underflows: the reference panics (fixed.rs:133)
+            status[i] = DCDF_ERR_OVERFLOW;
+            continue;
+        }
+        maxbits[i] = 62u - (1u + (lg > 0.0 ? (uint32_t)lg : 0u));
+    }
+    K2R_HIP(hipMemcpy(d_bits.p, maxbits.data(), n * 4, hipMemcpyHostToDevice));
+    if (dtype == DCDF_F32) hipLaunchKernelGGL((k_suggest<float, 2>), dim3(grid), dim3(256), 0, 0, d_views.as<SfView>(), d_bits.as<uint32_t>(), bpt, d_part.as<SfPartial>());
+    else hipLaunchKernelGGL((k_suggest<double, 2>), dim3(grid), dim3(256), 0, 0, d_views.as<SfView>(), d_bits.as<uint32_t>(), bpt, d_part.as<SfPartial>());
+    K2R_HIP(hipGetLastError());
+    K2R_HIP(hipMemcpy(part.data(), d_part.p, (size_t)grid * sizeof(SfPartial), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        out_round[i] = 0;
+        out_bits[i] = 0;
+        if (all_nan[i] || status[i] != DCDF_OK) continue;
+        uint32_t bits = 0, frac = 0;
+        for (uint32_t b = 0; b < bpt; b++) {
+            bits = std::max(bits, part[i * bpt + b].bits);
+            frac |= part[i * bpt + b].frac;
+        }
+        out_round[i] = frac ? 1 : 0;
+        out_bits[i] = (int32_t)(frac ? maxbits[i] : bits);
+    }
+    return DCDF_OK;
+}
+}  // namespace k2r
+
 extern "C" int dcdf_suggest_fraction(const dcdf_tile_desc* tile, int mem, int32_t* out_round, int32_t* out_bits) {
     if (!tile || !out_round || !out_bits || !tile->base) return DCDF_ERR_BAD_ARG;
     if (tile->dtype != DCDF_F32 && tile->dtype != DCDF_F64) return DCDF_ERR_BAD_ARG;
@@ -111,59 +190,30 @@ extern "C" int dcdf_suggest_fraction(const dcdf_tile_desc* tile, int mem, int32_
     if (!rt.ok) return DCDF_ERR_NO_DEVICE;
     K2R_HIP(hipSetDevice(rt.device));
     const size_t esz = tile->dtype == DCDF_F32 ? 4 : 8;
-    SfView v{tile->base, tile->stride_t, tile->stride_r, tile->stride_c, tile->instants, tile->rows, tile->cols};
+    dcdf_tile_desc dev = *tile;
     DevBuf staged;
-    if (mem == DCDF_MEM_HOST) {  // pack the view densely and upload it
+    if (mem == DCDF_MEM_HOST) {  // pack the view densely (row by row) and upload it
         std::vector<char> dense(n * esz);
         const char* src = (const char*)tile->base;
         size_t o = 0;
         for (uint32_t t = 0; t < tile->instants; t++)
-            for (uint32_t r = 0; r < tile->rows; r++)
-                for (uint32_t c = 0; c < tile->cols; c++, o += esz)
-                    std::memcpy(&dense[o], src + ((int64_t)t * tile->stride_t + (int64_t)r * tile->stride_r + (int64_t)c * tile->stride_c) * (int64_t)esz, esz);
+            for (uint32_t r = 0; r < tile->rows; r++) {
+                const char* row = src + ((int64_t)t * tile->stride_t + (int64_t)r * tile->stride_r) * (int64_t)esz;
+                if (tile->stride_c == 1) {
+                    std::memcpy(&dense[o], row, (size_t)tile->cols * esz);
+                    o += (size_t)tile->cols * esz;
+                } else {
+                    for (uint32_t c = 0; c < tile->cols; c++, o += esz) std::memcpy(&dense[o], row + (int64_t)c * tile->stride_c * (int64_t)esz, esz);
+                }
+            }
         K2R_HIP(staged.alloc(n * esz));
         K2R_HIP(hipMemcpy(staged.p, dense.data(), n * esz, hipMemcpyHostToDevice));
-        v = SfView{staged.p, (int64_t)tile->rows * tile->cols, (int64_t)tile->cols, 1, tile->instants, tile->rows, tile->cols};
+        dev.base = staged.p;
+        dev.stride_t = (int64_t)tile->rows * tile->cols;
+        dev.stride_r = tile->cols;
+        dev.stride_c = 1;
     }
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)rt.cus * 8);
-    DevBuf d_part;
-    K2R_HIP(d_part.alloc(grid * sizeof(SfPartial)));
-    std::vector<SfPartial> part(grid);
-    // pass 1
-    if (tile->dtype == DCDF_F32) hipLaunchKernelGGL((k_suggest<float, 1>), dim3(grid), dim3(256), 0, 0, v, n, 0u, d_part.as<SfPartial>());
-    else hipLaunchKernelGGL((k_suggest<double, 1>), dim3(grid), dim3(256), 0, 0, v, n, 0u, d_part.as<SfPartial>());
-    K2R_HIP(hipGetLastError());
-    K2R_HIP(hipMemcpy(part.data(), d_part.p, grid * sizeof(SfPartial), hipMemcpyDeviceToHost));
-    bool seen = false;
-    double mx = 0.0;
-    for (const SfPartial& p : part)
-        if (p.seen) {
-            mx = seen ? std::max(mx, p.max) : p.max;
-            seen = true;
-        }
-    if (!seen) {  // all NaN (fixed.rs:124-127)
-        *out_round = 0;
-        *out_bits = 0;
-        return DCDF_OK;
-    }
-    // whole_bits = 1 + log2(max).floor() as usize  (saturating float->usize cast: negative / NaN -> 0), fixed.rs:129
-    const double lg = std::floor(std::log2(mx));
-    if (lg > 61.0) return DCDF_ERR_OVERFLOW;  // TOTAL_BITS - whole_bits underflows: the reference panics (fixed.rs:133)
-    const uint32_t whole_bits = 1u + (lg > 0.0 ? (uint32_t)lg : 0u);
-    const uint32_t max_fraction_bits = 62u - whole_bits;
-    // pass 2
-    if (tile->dtype == DCDF_F32)
-        hipLaunchKernelGGL((k_suggest<float, 2>), dim3(grid), dim3(256), 0, 0, v, n, max_fraction_bits, d_part.as<SfPartial>());
-    else
-        hipLaunchKernelGGL((k_suggest<double, 2>), dim3(grid), dim3(256), 0, 0, v, n, max_fraction_bits, d_part.as<SfPartial>());
-    K2R_HIP(hipGetLastError());
-    K2R_HIP(hipMemcpy(part.data(), d_part.p, grid * sizeof(SfPartial), hipMemcpyDeviceToHost));
-    uint32_t bits = 0, frac = 0;
-    for (const SfPartial& p : part) {
-        bits = std::max(bits, p.bits);
-        frac |= p.frac;
-    }
-    *out_round = frac ? 1 : 0;
-    *out_bits = (int32_t)(frac ? max_fraction_bits : bits);
-    return DCDF_OK;
+    int32_t st = DCDF_OK;
+    const int rc = suggest_fraction_batch(&dev, 1, out_round, out_bits, &st);
+    return rc != DCDF_OK ? rc : st;
 }

@@ -21,9 +21,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "k2r_encode.h"
@@ -177,10 +179,10 @@ int hash_objects(const std::vector<const std::string*>& objs, std::vector<std::s
     return DCDF_OK;
 }
 // resolver.save: remember the object under its CID (content addressing makes identical objects one object)
-void save(Ctx& cx, const std::string& cid, const std::string& obj) {
+void save(Ctx& cx, const std::string& cid, std::string obj) {
     if (cx.by_cid.count(cid)) return;
     cx.by_cid[cid] = cx.objects.size();
-    cx.objects.push_back(obj);
+    cx.objects.push_back(std::move(obj));
     cx.cids.push_back(cid);
 }
 // Dac::from(values).write_to on the device
@@ -199,10 +201,27 @@ int dac_bytes(const std::vector<int64_t>& v, std::string& out) {
     K2R_HIP(hipMemcpy(&out[0], d_out.p, len, hipMemcpyDeviceToHost));
     return DCDF_OK;
 }
+}  // namespace
+namespace k2r {
+int suggest_fraction_batch(const dcdf_tile_desc* tiles, size_t n, int32_t* out_round, int32_t* out_bits, int32_t* status);
+}
+namespace {
 uint32_t levels_needed(uint64_t side, int k) { return ref_levels(side, (uint32_t)k); }  // superchunk.rs:98-101 (f64 formula)
 
 // One Superchunk::build over the DEVICE view `buf` (superchunk.rs:88-270).
+struct StepTimer {  // K2R_SC_TIMING=1: wall time of the assembly's steps on stderr (diagnostics)
+    const bool on = std::getenv("K2R_SC_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "k2r-sc %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size_t n_levels, Level* out) {
+    StepTimer tm;
     const int k = cx.k;
     const uint32_t instants = buf.instants, rows = buf.rows, cols = buf.cols;
     const uint32_t total_levels = levels_needed(std::max(rows, cols), k);
@@ -258,6 +277,7 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
         for (size_t q = 0; q < mt.size(); q++)
             std::memcpy(&mm[2ull * mt_tile[q] * instants], &got[2ull * q * instants], 16ull * instants);
     }
+    tm.lap("tile min/max");
     // ---- elision, sub-builds (superchunk.rs:144-181) ----
     std::vector<char> elided(n_tiles, 1);
     struct Sub {
@@ -270,6 +290,29 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
     std::vector<Sub> subs;
     std::vector<dcdf_tile_desc> chunk_descs;
     std::vector<size_t> chunk_sub;
+    auto can_elide_tile = [&](size_t i) {
+        for (uint32_t t = 0; t < instants; t++)
+            if (mm[2ull * (i * instants + t)] != mm[2ull * (i * instants + t) + 1]) return false;
+        return true;
+    };
+    // fractional bits of every float tile that will be built (fixed.rs:96-159), for the whole level at once
+    std::vector<size_t> frac_of(n_tiles, 0);
+    std::vector<int32_t> frac_rnd, frac_bits, frac_st;
+    if (buf.dtype == DCDF_F32 || buf.dtype == DCDF_F64) {
+        std::vector<dcdf_tile_desc> ft;
+        for (size_t i = 0; i < n_tiles; i++)
+            if (inside[i] && !can_elide_tile(i)) {
+                frac_of[i] = ft.size();
+                ft.push_back(tiles[i]);
+            }
+        frac_rnd.resize(ft.size());
+        frac_bits.resize(ft.size());
+        frac_st.resize(ft.size());
+        if (!ft.empty()) {
+            const int rc = suggest_fraction_batch(ft.data(), ft.size(), frac_rnd.data(), frac_bits.data(), frac_st.data());
+            if (rc != DCDF_OK) return rc;
+        }
+    }
     for (size_t i = 0; i < n_tiles; i++) {
         if (!inside[i]) continue;
         bool can_elide = true;
@@ -280,11 +323,11 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
         bool build_subchunk = at_bottom;
         if (!at_bottom) build_subchunk = levels_needed(std::max(t.rows, t.cols), k) <= sublevels[0];  // superchunk.rs:155-165
         if (t.dtype == DCDF_F32 || t.dtype == DCDF_F64) {  // sub_buffer.compute_fractional_bits() (mmbuffer.rs:596-613)
-            int32_t rnd = 0, bits = 0;
-            const int rc = dcdf_suggest_fraction(&t, DCDF_MEM_DEVICE, &rnd, &bits);
-            if (rc != DCDF_OK) return rc;
+            const size_t fi = frac_of[i];  // (all tiles of the level in two launches, before this loop)
+            if (frac_st[fi] != DCDF_OK) return frac_st[fi];
+            int32_t bits = frac_bits[fi];
             if (t.round) bits = std::min<int32_t>(bits, t.fractional_bits);
-            else if (rnd) return DCDF_ERR_PRECISION;  // panic!("loss of precision")
+            else if (frac_rnd[fi]) return DCDF_ERR_PRECISION;  // panic!("loss of precision")
             t.fractional_bits = (uint8_t)bits;
         }
         Sub s{};
@@ -304,26 +347,71 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
         }
         subs.push_back(std::move(s));
     }
-    if (!chunk_descs.empty()) {  // every Chunk::build of this level in one launch (superchunk.rs:169)
-        dcdf_encoded* enc = nullptr;
-        const int rc = dcdf_chunk_build_batch(chunk_descs.data(), chunk_descs.size(), k, DCDF_MEM_DEVICE, &enc);
-        if (rc != DCDF_OK) return rc;
-        int bad = DCDF_OK;
-        for (size_t q = 0; q < chunk_descs.size(); q++) {
-            if (enc[q].status != DCDF_OK) {
-                bad = enc[q].status;
-                break;
+    std::vector<std::string> chunk_cid(subs.size());  // CIDs of the sub-chunk objects, hashed where their bytes lie (HBM)
+    if (!chunk_descs.empty()) {
+        // every Chunk::build of this level in ONE launch (superchunk.rs:169) on a device-resident session: the objects' SHA-256
+        // is taken on the device from the encoder's own buffers (dcdf_encoder_object_sha256) and the bytes come to the host in
+        // one packed copy (dcdf_encoder_gather) -- no per-tile copies, no re-upload for hashing
+        struct EncGuard {
+            dcdf_encoder* e = nullptr;
+            ~EncGuard() {
+                if (e) dcdf_encoder_destroy(e);
             }
-            Sub& s = subs[chunk_sub[q]];
-            s.obj = header(2);      // NODE_MMSTRUCT3
-            s.obj.push_back(4);     // NODE_SUBCHUNK (mmstruct.rs:215-218)
-            s.obj.append((const char*)enc[q].bytes, enc[q].len);
-            s.size = enc[q].len + 1;
-            s.snapshots = enc[q].snapshots;
-            s.logs = enc[q].logs;
+        } g;
+        tm.lap("fractional bits, tiling");
+        int rc = dcdf_encoder_create(chunk_descs.data(), chunk_descs.size(), k, 0, &g.e);
+        if (rc != DCDF_OK) return rc;
+        tm.lap("encoder_create");
+        rc = dcdf_encoder_run(g.e, nullptr);
+        if (rc != DCDF_OK) return rc;
+        tm.lap("encoder_run");
+        const size_t nc = chunk_descs.size();
+        for (size_t q = 0; q < nc; q++) {
+            int32_t st = 0;
+            rc = dcdf_encoder_result(g.e, q, &st, nullptr, nullptr, nullptr, nullptr);
+            if (rc != DCDF_OK) return rc;
+            if (st != DCDF_OK) return st;
         }
-        dcdf_free_encoded(enc, chunk_descs.size());
-        if (bad != DCDF_OK) return bad;
+        // SHA-256 of a 1.4 MB object is one serial chain on one lane (≈ 150 ms for the 256 objects of a 4096^2 level): it runs on
+        // the session's stream from a helper thread while this thread gathers the bytes (own stream) and frames the objects
+        std::vector<uint8_t> dig(nc * 32);
+        int sha_rc = DCDF_OK;
+        std::thread sha([&] { sha_rc = dcdf_encoder_object_sha256(g.e, dig.data(), nullptr); });
+        struct Join {
+            std::thread& t;
+            ~Join() {
+                if (t.joinable()) t.join();
+            }
+        } join{sha};
+        uint64_t packed = 0, mmw = 0;
+        rc = dcdf_encoder_gather_size(g.e, &packed, &mmw);
+        if (rc != DCDF_OK) return rc;
+        std::vector<uint8_t> bytes(packed ? packed : 1);
+        std::vector<uint64_t> offs(nc), lens(nc);
+        rc = dcdf_encoder_gather(g.e, bytes.data(), bytes.size(), offs.data(), lens.data(), nullptr);
+        if (rc != DCDF_OK) return rc;
+        tm.lap("gather");
+        for (size_t q = 0; q < nc; q++) {
+            uint64_t len = 0;
+            uint32_t ns = 0, nl = 0;
+            int32_t st = 0;
+            (void)dcdf_encoder_result(g.e, q, &st, &len, &ns, &nl, nullptr);
+            Sub& s = subs[chunk_sub[q]];
+            const std::string hd = header(2);  // NODE_MMSTRUCT3
+            s.obj.resize(hd.size() + 1 + lens[q]);
+            std::memcpy(&s.obj[0], hd.data(), hd.size());
+            s.obj[hd.size()] = 4;  // NODE_SUBCHUNK (mmstruct.rs:215-218)
+            std::memcpy(&s.obj[hd.size() + 1], bytes.data() + offs[q], lens[q]);
+            s.size = lens[q] + 1;
+            s.snapshots = ns;
+            s.logs = nl;
+        }
+        tm.lap("framing");
+        sha.join();
+        if (sha_rc != DCDF_OK) return sha_rc;
+        for (size_t q = 0; q < nc; q++)
+            chunk_cid[chunk_sub[q]] = std::string("\x01\x12\x12\x20", 4) + std::string((const char*)dig.data() + 32 * q, 32);
+        tm.lap("object sha256 (rest)");
     }
     // ---- instant-major min / max (superchunk.rs:190-198) ----
     std::vector<int64_t> mins(n_tiles * (size_t)instants), maxs(n_tiles * (size_t)instants);
@@ -333,11 +421,18 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             maxs[(size_t)t * n_tiles + i] = mm[2ull * (i * instants + t) + 1];
         }
     // ---- references with de-duplication (superchunk.rs:199-236) ----
-    std::vector<const std::string*> to_hash;
-    for (const Sub& s : subs) to_hash.push_back(&s.obj);
-    std::vector<std::string> cids;
-    int rc = hash_objects(to_hash, cids);
+    std::vector<const std::string*> to_hash;  // (only the nested superchunk nodes are left to hash: small)
+    std::vector<size_t> hash_sub;
+    for (size_t q = 0; q < subs.size(); q++)
+        if (chunk_cid[q].empty()) {
+            to_hash.push_back(&subs[q].obj);
+            hash_sub.push_back(q);
+        }
+    std::vector<std::string> hashed;
+    int rc = hash_objects(to_hash, hashed);
     if (rc != DCDF_OK) return rc;
+    std::vector<std::string> cids(chunk_cid);
+    for (size_t j = 0; j < hash_sub.size(); j++) cids[hash_sub[j]] = hashed[j];
     std::vector<std::string> external;
     std::map<std::string, uint32_t> ext_index;
     std::vector<int64_t> refs(n_tiles, -1);
@@ -349,11 +444,11 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             out->elided++;
             continue;
         }
-        const Sub& s = subs[si];
+        Sub& s = subs[si];
         const std::string& cid = cids[si];
         si++;
         sizes += s.size;
-        save(cx, cid, s.obj);
+        save(cx, cid, std::move(s.obj));
         auto it = ext_index.find(cid);
         uint32_t index;
         if (it == ext_index.end()) {
@@ -367,6 +462,7 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
         out->snapshots += s.snapshots;
         out->logs += s.logs;
     }
+    tm.lap("references");
     std::string links = header(1);  // NODE_LINKS (links.rs:65-76)
     put_u32(links, (uint32_t)external.size());
     for (const std::string& c : external) links += c;
