@@ -96,6 +96,45 @@ def test_config2_full_raster_every_chunk_vs_oracle(dc):
     buf.free()
 
 
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_config1_all_1024_chunks_vs_oracle(dc, dtype):
+    """BASELINE configs[1] / SURVEY 8(d) config 2: 1024 independent [32, 256, 256] chunks, chunk c from seed 0xDCDF0002 + c, as
+    int32 and as int64 "fixed point" (odd values, 16 GiB), one launch each; EVERY chunk's bytes, counters and per-instant
+    (min, max) against the CPU oracle (one chunk per task on the host cores)."""
+    from dcdf_amd import _lib as L
+    from dcdf_amd.encoder import DeviceBuffer, Encoder, synth_fill
+    n, T, S = 1024, 32, 256
+    es = np.dtype(dtype).itemsize
+    code = L.DCDF_I32 if dtype == np.int32 else L.DCDF_I64
+    buf = DeviceBuffer(n * T * S * S * es)
+    descs = []
+    for c in range(n):
+        ptr = buf.ptr + c * T * S * S * es
+        synth_fill(ptr, code, 0xDCDF0002 + c, 0, T, 0, S, 0, S)
+        descs.append((ptr, code, (S * S, S, 1), (T, S, S)))
+    enc = Encoder(descs, k=2)
+    enc.run()
+    packed, goffs, glens, mm = enc.gather()
+    res = [enc.result(i) for i in range(n)]
+    assert all(r[0] == 0 for r in res)
+
+    def check(i):
+        host = buf.read(i * T * S * S * es, T * S * S * es, dtype).reshape(T, S, S)
+        ref, ns, nl, _ = O.chunk_build(host, want_snapshots=True)
+        ok = len(ref) == int(glens[i]) and packed[int(goffs[i]):int(goffs[i]) + int(glens[i])].tobytes() == ref and (ns, nl) == (res[i][2], res[i][3])
+        flat = host.reshape(T, -1)
+        m = mm[i * T:(i + 1) * T]
+        return ok and (m[:, 0] == flat.min(1)).all() and (m[:, 1] == flat.max(1)).all()
+
+    nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+    with ThreadPoolExecutor(nthr) as ex:
+        out = list(ex.map(check, range(n)))
+    bad = [i for i, ok in enumerate(out) if not ok]
+    assert not bad, "chunks differing from the oracle: %s" % bad[:10]
+    enc.close()
+    buf.free()
+
+
 def test_config4_queries_split_at_tile_and_segment_boundaries(dc):
     """BASELINE configs[4] / SURVEY 8(d) config 5 on a sub-raster that has every kind of boundary: 70 x 768 x 768 cells of
     the configs[2] raster (3 time segments of 32/32/6 instants x 3 x 3 tiles = 27 chunks).  10 000 fill_window + 10 000
