@@ -1109,6 +1109,9 @@ k_search_emit(const WinQuery* __restrict__ qs, const SearchItem* __restrict__ it
     const uint32_t wc = Q.right - Q.left, nbits = (Q.bottom - Q.top) * wc;
     const uint32_t* bw = bits + I.bits_off;
     uint32_t* o = out + 3 * offs[it];
+    // origin of the chunk inside its raster (dcdf_raster_search_batch; zero for chunk-level searches): a search does not use
+    // out_off / _pad otherwise
+    const uint32_t ot = Q._pad, orow = (uint32_t)Q.out_off, ocol = (uint32_t)(Q.out_off >> 32);
     if (I.w0 != SI_FLAT) {  // the pieces' bitmaps (64 rows x 2 words) of the wave walk: rows in order, pieces left to right
         for (uint32_t r = Q.top; r < Q.bottom; r++) {
             const uint32_t rb = (r - Q.top) >> 6, rr = (r - Q.top) & 63u;
@@ -1117,9 +1120,9 @@ k_search_emit(const WinQuery* __restrict__ qs, const SearchItem* __restrict__ it
                 while (x) {
                     const uint32_t j = (uint32_t)__builtin_ctz(x);
                     x &= x - 1;
-                    o[0] = I.instant;
-                    o[1] = r;
-                    o[2] = Q.left + 32u * cw + j;
+                    o[0] = ot + I.instant;
+                    o[1] = orow + r;
+                    o[2] = ocol + Q.left + 32u * cw + j;
                     o += 3;
                 }
             }
@@ -1131,9 +1134,9 @@ k_search_emit(const WinQuery* __restrict__ qs, const SearchItem* __restrict__ it
         while (x) {
             const uint32_t p = 32 * w + (uint32_t)__builtin_ctz(x);
             x &= x - 1;
-            o[0] = I.instant;
-            o[1] = Q.top + p / wc;
-            o[2] = Q.left + p % wc;
+            o[0] = ot + I.instant;
+            o[1] = orow + Q.top + p / wc;
+            o[2] = ocol + Q.left + p % wc;
             o += 3;
         }
     }
@@ -1629,8 +1632,11 @@ extern "C" int dcdf_query_fill_cell_batch(dcdf_chunk* const* chunks, const uint3
 // window meets, so that a frontier level never exceeds what a wave's LDS queue holds (k2r::WQ_CAP)
 // node_wise: pieces of at most 64 x 64 cells from the window's origin (k_window_wave2); else the squares of the chunk's 32-grid
 // the window meets (k_window_wave)
-static void window_items(uint32_t chunk, const dcdf_cube& c, uint64_t out_base, std::vector<WinItem>& items, bool node_wise) {
-    const uint64_t wr = c.bottom - c.top, wc = c.right - c.left;
+// out_base = element offset of cell (c.start, c.top, c.left); sr / st = row and instant strides of the array the window is
+// written into (0 = the window's own dense layout; a piece of a larger window passes the parent's)
+static void window_items(uint32_t chunk, const dcdf_cube& c, uint64_t out_base, std::vector<WinItem>& items, bool node_wise,
+                         uint64_t sr = 0, uint64_t st = 0) {
+    const uint64_t wc = sr ? sr : (uint64_t)(c.right - c.left), wr_wc = st ? st : (uint64_t)(c.bottom - c.top) * wc;
     const uint32_t step = node_wise ? 64u : 32u;
     for (uint32_t t = c.start; t < c.end; t++)
         for (uint32_t r = node_wise ? c.top : (c.top & ~31u); r < c.bottom; r += step)
@@ -1643,7 +1649,7 @@ static void window_items(uint32_t chunk, const dcdf_cube& c, uint64_t out_base, 
                 it.left = (uint16_t)std::max(cc, c.left);
                 it.right = (uint16_t)std::min(cc + step, c.right);
                 it.out_sr = (uint32_t)wc;
-                it.out_off = out_base + ((uint64_t)(t - c.start) * wr + (it.top - c.top)) * wc + (it.left - c.left);
+                it.out_off = out_base + (uint64_t)(t - c.start) * wr_wc + (uint64_t)(it.top - c.top) * wc + (it.left - c.left);
                 items.push_back(it);
             }
 }
@@ -1743,12 +1749,19 @@ static void dedup_chunks(dcdf_chunk* const* chunks, size_t nq, std::vector<uint3
         idx[q] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), (const dcdf_chunk*)chunks[q]) - uniq.begin());
 }
 
+struct SearchCtx {  // a raster's view of its chunks (dcdf_raster_search_batch): nothing to de-duplicate or upload per call
+    const DevBuf* refs;        // ChunkRef table, one entry per chunk of the raster
+    const uint32_t* chunk_of;  // per query: index into it
+    const uint32_t* origin;    // per query: (instant, row, col) of the chunk inside the raster, added to every triple
+    bool node_wise, all_narrow;
+};
+
 static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper,
                        size_t nq, uint32_t* out, size_t cap, uint64_t* counts, uint64_t* offsets, size_t* total_out,
-                       float* kernel_ms, int out_mem = DCDF_MEM_HOST) {
+                       float* kernel_ms, int out_mem = DCDF_MEM_HOST, const SearchCtx* ctx = nullptr) {
     std::vector<uint32_t> cidx;
     std::vector<const dcdf_chunk*> uniq;
-    dedup_chunks(chunks, nq, cidx, uniq);
+    if (!ctx) dedup_chunks(chunks, nq, cidx, uniq);
     std::vector<WinQuery> qs(nq);
     std::vector<SearchItem> items;
     // k = 2 chunks: the wave-cooperative walk of fill_window marks the matches (one wave per piece of <= 64 x 64 cells and
@@ -1756,6 +1769,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     // decoded and tested cell by cell (k_search_cells) into a flat per-item bitmap
     bool node_wise = std::getenv("K2R_SEARCH_DFS") == nullptr;  // (diagnostics: A/B against the cell-by-cell kernel)
     for (const dcdf_chunk* u : uniq) node_wise = node_wise && node_kernel_ok(u);
+    if (ctx) node_wise = node_wise && ctx->node_wise;
     std::vector<WinItem> witems;
     std::vector<SearchExtra> sx;
     std::vector<uint8_t> item_quirk;  // per item of the decode-and-test kernel
@@ -1767,7 +1781,11 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         if (!cube_in(chunks[q], c)) return DCDF_ERR_BOUNDS;
         WinQuery& Q = qs[q];
         Q = WinQuery{};
-        Q.chunk = cidx[q];
+        Q.chunk = ctx ? ctx->chunk_of[q] : cidx[q];
+        if (ctx) {
+            Q._pad = ctx->origin[3 * q];
+            Q.out_off = (uint64_t)ctx->origin[3 * q + 1] | (uint64_t)ctx->origin[3 * q + 2] << 32;
+        }
         Q.start = c.start; Q.end = c.end; Q.top = c.top; Q.bottom = c.bottom; Q.left = c.left; Q.right = c.right;
         Q.lower = std::min(lower[q], upper[q]);  // helpers.rs:7-16 via chunk.rs:214
         Q.upper = std::max(lower[q], upper[q]);
@@ -1802,10 +1820,13 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     for (size_t q = 0; q < nq; q++) counts[q] = 0;
     float ms_total = 0.f;
     std::vector<uint32_t> item_counts(items.size());
-    DevBuf d_refs, d_qs, d_items, d_bits, d_wbits, d_witems, d_sx, d_counts, d_offs, d_out, d_quirk;
+    DevBuf d_refs_own, d_qs, d_items, d_bits, d_wbits, d_witems, d_sx, d_counts, d_offs, d_out, d_quirk;
     if (!items.empty()) {
-        int rc = upload_refs(chunks, cidx, uniq.size(), uniq, d_refs);
-        if (rc != DCDF_OK) return rc;
+        if (!ctx) {
+            int rc = upload_refs(chunks, cidx, uniq.size(), uniq, d_refs_own);
+            if (rc != DCDF_OK) return rc;
+        }
+        const DevBuf& d_refs = ctx ? *ctx->refs : d_refs_own;
         K2R_HIP(d_qs.alloc(nq * sizeof(WinQuery)));
         K2R_HIP(hipMemcpy(d_qs.p, qs.data(), nq * sizeof(WinQuery), hipMemcpyHostToDevice));
         K2R_HIP(d_items.alloc(items.size() * sizeof(SearchItem)));
@@ -1831,6 +1852,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
         if (nw) {
             bool all_narrow = true;
             for (const dcdf_chunk* u : uniq) all_narrow = all_narrow && u->narrow32;
+            if (ctx) all_narrow = ctx->all_narrow;
             if (all_narrow)
                 hipLaunchKernelGGL((k_window_wave2<4, false, true, int32_t>), dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
                                    d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
@@ -2012,4 +2034,156 @@ extern "C" int dcdf_query_fill_window_batch(dcdf_chunk* const* chunks, const dcd
 extern "C" int dcdf_query_fill_window_batch_typed(dcdf_chunk* const* chunks, const dcdf_cube* cubes, size_t nq, void* out,
                                                   int32_t out_dtype, int out_mem, const uint64_t* out_offset, float* kernel_ms) {
     return fill_window_batch_impl(chunks, cubes, nq, out, out_dtype, out_mem, out_offset, kernel_ms);
+}
+
+
+// ---- a tiled, time-segmented raster of opened chunks: the routing of the layers above, natively ---------------------------------
+// Variable::append cuts [instants, rows, cols] into time segments of chunk_size instants (dataset.rs:838) and Superchunk::build
+// cuts each segment into tile x tile sub-arrays (superchunk.rs:127-181); reads are routed back the same way (Span::fill_window
+// span.rs:190-216 over time, Superchunk::subchunks_for superchunk.rs:589-633 over rows / cols).  dcdf_raster does that split for a
+// whole batch of dataset-level cubes on the host in C++ and decodes every piece in ONE launch straight into its place in the
+// caller's window (the pieces carry the parent window's strides): no per-piece copies, no reassembly, the chunk table uploaded once.
+struct dcdf_raster {
+    std::vector<dcdf_chunk*> chunks;  // [(segment * nti + ti) * ntj + tj]
+    uint32_t T = 0, R = 0, C = 0, tile = 0, cs = 0, nseg = 0, nti = 0, ntj = 0;
+    DevBuf d_refs;
+    bool all_wave = true, all_node = true, all_narrow = true;
+};
+extern "C" int dcdf_raster_create(dcdf_chunk* const* chunks, size_t n_chunks, const uint32_t shape[3], uint32_t tile, uint32_t chunk_size,
+                                  dcdf_raster** out) {
+    if (!chunks || !shape || !out || tile == 0 || chunk_size == 0 || shape[0] == 0 || shape[1] == 0 || shape[2] == 0) return DCDF_ERR_BAD_ARG;
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    std::unique_ptr<dcdf_raster> r(new (std::nothrow) dcdf_raster());
+    if (!r) return DCDF_ERR_NOMEM;
+    r->T = shape[0]; r->R = shape[1]; r->C = shape[2]; r->tile = tile; r->cs = chunk_size;
+    r->nseg = (r->T + chunk_size - 1) / chunk_size;
+    r->nti = (r->R + tile - 1) / tile;
+    r->ntj = (r->C + tile - 1) / tile;
+    if ((uint64_t)r->nseg * r->nti * r->ntj != n_chunks) return DCDF_ERR_BAD_ARG;
+    r->chunks.assign(chunks, chunks + n_chunks);
+    std::vector<ChunkRef> refs(n_chunks);
+    for (size_t i = 0; i < n_chunks; i++) {
+        const dcdf_chunk* h = chunks[i];
+        if (!h) return DCDF_ERR_BAD_ARG;
+        const uint32_t seg = (uint32_t)(i / ((size_t)r->nti * r->ntj)), ti = (uint32_t)(i / r->ntj % r->nti), tj = (uint32_t)(i % r->ntj);
+        // every chunk must have the shape its place in the grid gives it
+        if (h->instants != std::min(chunk_size, r->T - seg * chunk_size) || h->rows != std::min(tile, r->R - ti * tile) ||
+            h->cols != std::min(tile, r->C - tj * tile))
+            return DCDF_ERR_BAD_ARG;
+        refs[i] = make_ref(h);
+        r->all_wave = r->all_wave && wave_kernel_ok(h);
+        r->all_node = r->all_node && node_kernel_ok(h);
+        r->all_narrow = r->all_narrow && h->narrow32;
+    }
+    K2R_HIP(r->d_refs.alloc(n_chunks * sizeof(ChunkRef)));
+    K2R_HIP(hipMemcpy(r->d_refs.p, refs.data(), n_chunks * sizeof(ChunkRef), hipMemcpyHostToDevice));
+    *out = r.release();
+    return DCDF_OK;
+}
+extern "C" void dcdf_raster_destroy(dcdf_raster* r) { delete r; }
+
+// the pieces of one dataset-level cube: f(chunk id, local cube, raster origin of the chunk)
+template <class F>
+static void raster_pieces(const dcdf_raster* r, const dcdf_cube& c, F&& f) {
+    for (uint32_t seg = c.start / r->cs; seg <= (c.end - 1) / r->cs; seg++)
+        for (uint32_t ti = c.top / r->tile; ti <= (c.bottom - 1) / r->tile; ti++)
+            for (uint32_t tj = c.left / r->tile; tj <= (c.right - 1) / r->tile; tj++) {
+                const uint32_t t0 = seg * r->cs, r0 = ti * r->tile, c0 = tj * r->tile;
+                const dcdf_cube l{std::max(c.start, t0) - t0, std::min(c.end, t0 + r->cs) - t0, std::max(c.top, r0) - r0,
+                                  std::min(c.bottom, r0 + r->tile) - r0, std::max(c.left, c0) - c0, std::min(c.right, c0 + r->tile) - c0};
+                f((uint32_t)(((uint64_t)seg * r->nti + ti) * r->ntj + tj), l, t0, r0, c0);
+            }
+}
+extern "C" int dcdf_raster_fill_window_batch(const dcdf_raster* r, const dcdf_cube* cubes, size_t nq, void* out, int32_t out_dtype,
+                                             int out_mem, const uint64_t* out_offset, float* kernel_ms) {
+    if (!r || !cubes || !out || !out_offset || nq == 0) return DCDF_ERR_BAD_ARG;
+    if (out_dtype != DCDF_I32 && out_dtype != DCDF_I64 && out_dtype != DCDF_F32 && out_dtype != DCDF_F64) return DCDF_ERR_BAD_ARG;
+    if (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE) return DCDF_ERR_BAD_ARG;
+    if (!r->all_wave) return DCDF_ERR_UNSUPPORTED;  // arities beyond the wave walk (k * k > 64): use the per-chunk entry points
+    const size_t es = (out_dtype == DCDF_I32 || out_dtype == DCDF_F32) ? 4 : 8;
+    const bool to_dev = out_mem == DCDF_MEM_DEVICE;
+    std::vector<WinItem> items;
+    uint64_t total = 0;
+    bool dense = true;
+    for (size_t q = 0; q < nq; q++) {
+        const dcdf_cube c = norm_cube(cubes[q]);
+        if (c.end > r->T || c.bottom > r->R || c.right > r->C) return DCDF_ERR_BOUNDS;
+        const uint64_t wt = c.end - c.start, wr = c.bottom - c.top, wc = c.right - c.left;
+        dense = dense && out_offset[q] == total + out_offset[0];
+        const uint64_t base = to_dev ? out_offset[q] : total;
+        total += wt * wr * wc;
+        if (wt * wr * wc == 0) continue;
+        raster_pieces(r, c, [&](uint32_t cid, const dcdf_cube& l, uint32_t t0, uint32_t r0, uint32_t c0) {
+            const uint64_t at = base + ((uint64_t)(t0 + l.start - c.start) * wr + (r0 + l.top - c.top)) * wc + (c0 + l.left - c.left);
+            window_items(cid, l, at, items, r->all_node, wc, wr * wc);
+        });
+    }
+    if (items.empty()) return DCDF_OK;
+    if (items.size() > 0xfffffff0ull) return DCDF_ERR_CAPACITY;
+    DevBuf d_o;
+    if (!to_dev) K2R_HIP(d_o.alloc(total * es));
+    EventPair ev;
+    K2R_HIP(ev.create());
+    const int rc = launch_window_items(r->d_refs, items, to_dev ? out : d_o.p, out_dtype, ev.e0, ev.e1, r->all_node, r->all_narrow);
+    if (rc != DCDF_OK) return rc;
+    if (!to_dev) {
+        if (dense) {
+            K2R_HIP(hipMemcpy((uint8_t*)out + out_offset[0] * es, d_o.p, total * es, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<uint8_t> tmp(total * es);
+            K2R_HIP(hipMemcpy(tmp.data(), d_o.p, total * es, hipMemcpyDeviceToHost));
+            uint64_t run = 0;
+            for (size_t q = 0; q < nq; q++) {
+                const dcdf_cube c = norm_cube(cubes[q]);
+                const uint64_t cells = (uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left);
+                if (cells) std::memcpy((uint8_t*)out + out_offset[q] * es, tmp.data() + run * es, cells * es);
+                run += cells;
+            }
+        }
+    }
+    float ms = 0.f;
+    K2R_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    if (kernel_ms) *kernel_ms = ms;
+    return DCDF_OK;
+}
+extern "C" int dcdf_raster_search_batch(const dcdf_raster* r, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper, size_t nq,
+                                        uint32_t* out, size_t cap, int out_mem, uint64_t* counts, uint64_t* offsets, float* kernel_ms) {
+    if (!r || !cubes || !lower || !upper || !counts || !offsets || nq == 0 || (!out && cap)) return DCDF_ERR_BAD_ARG;
+    if (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE) return DCDF_ERR_BAD_ARG;
+    std::vector<dcdf_chunk*> sch;
+    std::vector<dcdf_cube> scube;
+    std::vector<int64_t> slo, shi;
+    std::vector<uint32_t> sorg, scid, first(nq + 1, 0);
+    sch.reserve(2 * nq); scube.reserve(2 * nq); slo.reserve(2 * nq); shi.reserve(2 * nq); sorg.reserve(6 * nq); scid.reserve(2 * nq);
+    for (size_t q = 0; q < nq; q++) {
+        const dcdf_cube c = norm_cube(cubes[q]);
+        if (c.end > r->T || c.bottom > r->R || c.right > r->C) return DCDF_ERR_BOUNDS;
+        if ((uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left) != 0)
+            raster_pieces(r, c, [&](uint32_t cid, const dcdf_cube& l, uint32_t t0, uint32_t r0, uint32_t c0) {
+                sch.push_back(r->chunks[cid]);
+                scid.push_back(cid);
+                scube.push_back(l);
+                slo.push_back(lower[q]);
+                shi.push_back(upper[q]);
+                sorg.push_back(t0);
+                sorg.push_back(r0);
+                sorg.push_back(c0);
+            });
+        first[q + 1] = (uint32_t)sch.size();
+    }
+    for (size_t q = 0; q < nq; q++) counts[q] = offsets[q] = 0;
+    if (sch.empty()) return DCDF_OK;
+    std::vector<uint64_t> scnt(sch.size()), soff(sch.size());
+    size_t total = 0;
+    // the pieces of one query follow each other (segments, then tile rows, then tile columns) and search_impl emits in
+    // query order, so a query's triples are contiguous; each is moved to raster coordinates as it is written
+    const SearchCtx ctx{&r->d_refs, scid.data(), sorg.data(), r->all_node, r->all_narrow};
+    const int rc = search_impl(sch.data(), scube.data(), slo.data(), shi.data(), sch.size(), out, cap, scnt.data(), soff.data(), &total, kernel_ms,
+                               out_mem, &ctx);
+    if (rc != DCDF_OK) return rc;
+    for (size_t q = 0; q < nq; q++) {
+        offsets[q] = first[q] < sch.size() ? soff[first[q]] : total;
+        for (uint32_t k = first[q]; k < first[q + 1]; k++) counts[q] += scnt[k];
+    }
+    return DCDF_OK;
 }

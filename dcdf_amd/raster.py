@@ -27,6 +27,72 @@ class EncodedRaster:
             raise ValueError("expected %d chunks" % (self.nseg * self.nti * self.ntj))
         self.chunks = list(chunks)
 
+        self._native = None
+
+    # ---- the same routing natively (dcdf_raster_*: split in C++, every piece decoded into its place by one launch) ---------
+    def _handle(self):
+        if self._native is None:
+            hs = (C.c_void_p * len(self.chunks))(*[c._h for c in self.chunks])
+            shp = (C.c_uint32 * 3)(*self.shape)
+            h = C.c_void_p()
+            L.check(L.lib().dcdf_raster_create(hs, C.c_size_t(len(self.chunks)), shp, self.tile, self.chunk_size, C.byref(h)), "raster_create")
+            self._native = h
+        return self._native
+
+    def close(self):
+        if getattr(self, "_native", None):
+            L.lib().dcdf_raster_destroy(self._native)
+            self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fill_windows_flat(self, cubes, dtype=np.int64, out_device_ptr=None, out_offset=None):
+        """fill_window of dataset-level cubes [n, 6] through dcdf_raster_fill_window_batch.  Host form: returns (flat array of
+        dtype, offsets uint64[n], kernel ms): window q is flat[offsets[q]:] shaped (t, r, c).  Device form (out_device_ptr +
+        out_offset in elements): the windows are written there, returns kernel ms."""
+        from .chunk import _ENC
+        q = np.ascontiguousarray(np.asarray(cubes, dtype=np.uint32).reshape(-1, 6))
+        dtype = np.dtype(dtype)
+        ms = C.c_float()
+        if out_device_ptr is None:
+            vol = ((q[:, 1].astype(np.int64) - q[:, 0]) * (q[:, 3].astype(np.int64) - q[:, 2]) * (q[:, 5].astype(np.int64) - q[:, 4])).astype(np.uint64)
+            off = np.zeros(len(q), dtype=np.uint64)
+            if len(q) > 1:
+                off[1:] = np.cumsum(vol)[:-1]
+            out = np.empty(max(1, int(vol.sum())), dtype=dtype)
+            L.check(L.lib().dcdf_raster_fill_window_batch(self._handle(), q.ctypes.data_as(C.POINTER(L.Cube)), C.c_size_t(len(q)),
+                                                          C.c_void_p(out.ctypes.data), _ENC[dtype], L.MEM_HOST, C.c_void_p(off.ctypes.data),
+                                                          C.byref(ms)), "raster_fill_window_batch")
+            return out, off, ms.value
+        off = np.ascontiguousarray(np.asarray(out_offset, dtype=np.uint64))
+        L.check(L.lib().dcdf_raster_fill_window_batch(self._handle(), q.ctypes.data_as(C.POINTER(L.Cube)), C.c_size_t(len(q)),
+                                                      C.c_void_p(out_device_ptr), _ENC[dtype], L.MEM_DEVICE, C.c_void_p(off.ctypes.data),
+                                                      C.byref(ms)), "raster_fill_window_batch")
+        return ms.value
+
+    def search_flat(self, cubes, lower, upper, out_device_ptr=None, cap=None):
+        """search of dataset-level cubes through dcdf_raster_search_batch: returns (triples uint32[hits, 3] in raster coordinates
+        -- or None when they stay on the device --, offsets, counts, kernel ms)."""
+        q = np.ascontiguousarray(np.asarray(cubes, dtype=np.uint32).reshape(-1, 6))
+        lo = np.ascontiguousarray(np.asarray(lower, dtype=np.int64))
+        hi = np.ascontiguousarray(np.asarray(upper, dtype=np.int64))
+        counts = np.zeros(len(q), dtype=np.uint64)
+        offs = np.zeros(len(q), dtype=np.uint64)
+        if cap is None:
+            cap = int(((q[:, 1].astype(np.int64) - q[:, 0]) * (q[:, 3].astype(np.int64) - q[:, 2]) * (q[:, 5].astype(np.int64) - q[:, 4])).sum())
+        ms = C.c_float()
+        trip = None if out_device_ptr else np.empty((max(cap, 1), 3), dtype=np.uint32)
+        L.check(L.lib().dcdf_raster_search_batch(self._handle(), q.ctypes.data_as(C.POINTER(L.Cube)), C.c_void_p(lo.ctypes.data),
+                                                 C.c_void_p(hi.ctypes.data), C.c_size_t(len(q)),
+                                                 C.c_void_p(out_device_ptr or trip.ctypes.data), C.c_size_t(cap),
+                                                 L.MEM_DEVICE if out_device_ptr else L.MEM_HOST, C.c_void_p(counts.ctypes.data),
+                                                 C.c_void_p(offs.ctypes.data), C.byref(ms)), "raster_search_batch")
+        return trip, offs, counts, ms.value
+
     @staticmethod
     def chunk_grid(shape, tile=256, chunk_size=32):
         """[(t0, t1, r0, r1, c0, c1)] of every chunk, in chunk-id order (segment-major, then tile row, tile col)."""

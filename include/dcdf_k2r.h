@@ -220,6 +220,26 @@ int dcdf_query_fill_cell_batch(dcdf_chunk* const* chunks, const uint32_t* cells,
 int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t* lens, size_t n, int mem, dcdf_chunk** out,
                           int32_t* status);
 
+/* ---- a whole raster of chunks: the routing of the layers above ------------------------------------------------------- */
+/* A variable as dcdf lays it out: time segments of chunk_size instants (Variable::append, dataset.rs:838), each cut into
+ * tile x tile sub-arrays (Superchunk::build, superchunk.rs:127-181); chunks[(segment * ntiles_r + ti) * ntiles_c + tj], every chunk
+ * with the shape its place gives it.  The handle keeps the chunk table on the device. */
+typedef struct dcdf_raster dcdf_raster;
+int dcdf_raster_create(dcdf_chunk* const* chunks, size_t n_chunks, const uint32_t shape[3], uint32_t tile, uint32_t chunk_size,
+                       dcdf_raster** out);
+void dcdf_raster_destroy(dcdf_raster* r);
+/* fill_window of nq dataset-level cubes (raster coordinates): each is split at segment / tile boundaries where Span::fill_window
+ * (span.rs:190-216) and Superchunk::subchunks_for (superchunk.rs:589-633) split it, every piece is decoded by the same launch
+ * straight into its place in the window; window q is dense [instants][rows][cols] of out_dtype at out + out_offset[q] (elements),
+ * host or device memory.  k * k > 64 chunks: DCDF_ERR_UNSUPPORTED (use the per-chunk entry points). */
+int dcdf_raster_fill_window_batch(const dcdf_raster* r, const dcdf_cube* cubes, size_t nq, void* out, int32_t out_dtype,
+                                  int out_mem, const uint64_t* out_offset, float* kernel_ms);
+/* search of nq dataset-level cubes: (instant, row, col) triples in RASTER coordinates (span.rs:231-270 adds the segment offset,
+ * superchunk.rs:516-585 the tile origin); query q's triples are out[3 * offsets[q] .. + 3 * counts[q]), ordered by piece
+ * (segment, tile row, tile col), sorted inside a piece. */
+int dcdf_raster_search_batch(const dcdf_raster* r, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper, size_t nq,
+                             uint32_t* out, size_t cap, int out_mem, uint64_t* counts, uint64_t* offsets, float* kernel_ms);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 /* fixed.rs:96-159 + mmbuffer.rs:596-613: per-tile suggest_fraction on the device; out_round = 1 for
  * Fraction::Round.  Host or device data per `mem`. */

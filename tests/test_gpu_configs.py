@@ -268,7 +268,7 @@ def test_out_capacity_retry_and_session_reuse(dc):
 
 def test_config4_one_million_queries_full_size(dc):
     """BASELINE configs[4] at full size: 1M random get_window + search_window queries against the encoded 4096x4096x365 raster
-    (tools/bench_query.py: chunks opened from the encoder's device buffers, typed device-resident results), 80 reassembled
+    (tools/bench_query.py: chunks opened from the encoder's device buffers, typed device-resident results; once through the chunk-level batch entry points with the routing in numpy and once through dcdf_raster_*), 80 reassembled
     answers per kind checked against the synthetic model cell by cell / hit by hit, and the totals against the size-independent
     facts of the workload (every query is answered; decoded cells == the cubes' volumes)."""
     import importlib.util
@@ -276,7 +276,60 @@ def test_config4_one_million_queries_full_size(dc):
     bq = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bq)
     res = bq.run(queries=1000000, batch=250000, segments=12, check=20, cpu_sample=0, host_results=False)
-    assert res["config"]["chunks"] == 3072 and res["config"]["answers_checked_vs_model"] == 160
+    assert res["config"]["chunks"] == 3072 and res["config"]["answers_checked_vs_model"] == 320
     assert res["fill_window"]["queries"] == 500000 and res["search_window"]["queries"] == 500000
     assert res["fill_window"]["cells"] > 2e9 and res["search_window"]["hits"] > 1e8
     assert res["open"]["seconds"] < 5.0
+
+
+def test_native_raster_routing_matches_the_python_routing(dc):
+    """dcdf_raster_fill_window_batch / dcdf_raster_search_batch (the split of Span::fill_window, span.rs:190-216, and
+    Superchunk::subchunks_for, superchunk.rs:589-633, in C++; every piece decoded straight into its window) against the raw
+    raster and against the Python routing over the per-chunk batch entry points."""
+    from dcdf_amd import synth
+    from dcdf_amd.encoder import DeviceBuffer, Encoder
+    from dcdf_amd.raster import EncodedRaster
+    shape = (70, 600, 520)  # ragged last segment (70 = 2 * 32 + 6), ragged tiles (600 = 2 * 256 + 88, 520 = 2 * 256 + 8)
+    buf, grid, descs, offs = _device_raster(0xDCDF0009, shape)
+    enc = Encoder(descs, k=2)
+    enc.run()
+    chunks = enc.open_chunks()
+    R = EncodedRaster(shape, chunks)
+    full = synth.cells(0xDCDF0009, 0, shape[0], 0, shape[1], 0, shape[2], np.int32)
+    rng = np.random.default_rng(9)
+    cubes = []
+    for _ in range(300):
+        t0 = int(rng.integers(0, shape[0])); t1 = min(shape[0], t0 + int(rng.integers(1, 40)))
+        r0 = int(rng.integers(0, shape[1])); r1 = min(shape[1], r0 + int(rng.integers(1, 300)))
+        c0 = int(rng.integers(0, shape[2])); c1 = min(shape[2], c0 + int(rng.integers(1, 300)))
+        cubes.append((t0, t1, r0, r1, c0, c1))
+    cubes.append((0, shape[0], 250, 262, 250, 262))     # crosses every segment and four tiles
+    cubes.append((31, 33, 0, shape[1], 255, 257))
+    flat, off, _ = R.fill_windows_flat(cubes, dtype=np.int32)
+    for q, c in enumerate(cubes):
+        exp = full[c[0]:c[1], c[2]:c[3], c[4]:c[5]]
+        np.testing.assert_array_equal(flat[int(off[q]):int(off[q]) + exp.size].reshape(exp.shape), exp)
+    # device-resident result at arbitrary element offsets
+    vol = [(c[1] - c[0]) * (c[3] - c[2]) * (c[5] - c[4]) for c in cubes[:20]]
+    doff = np.cumsum([5] + [v + 3 for v in vol[:-1]]).astype(np.uint64)
+    dev = DeviceBuffer(int(doff[-1] + vol[-1]) * 8)
+    R.fill_windows_flat(cubes[:20], dtype=np.int64, out_device_ptr=dev.ptr, out_offset=doff)
+    back = dev.read(0, int(doff[-1] + vol[-1]) * 8, np.int64)
+    for q, c in enumerate(cubes[:20]):
+        exp = full[c[0]:c[1], c[2]:c[3], c[4]:c[5]]
+        np.testing.assert_array_equal(back[int(doff[q]):int(doff[q]) + exp.size].reshape(exp.shape), exp)
+    # search: raster coordinates
+    lo = rng.integers(-3000, 3000, size=len(cubes))
+    hi = lo + rng.integers(0, 400, size=len(cubes))
+    trip, soff, cnt, _ = R.search_flat(cubes, lo, hi)
+    ref = R.search(np.array(cubes), lo, hi)              # the Python routing over dcdf_query_search_batch
+    for q, c in enumerate(cubes):
+        got = set(map(tuple, trip[int(soff[q]):int(soff[q]) + int(cnt[q])].tolist()))
+        sub = full[c[0]:c[1], c[2]:c[3], c[4]:c[5]]
+        want = set((int(a) + c[0], int(b) + c[2], int(d) + c[4]) for a, b, d in zip(*np.nonzero((sub >= lo[q]) & (sub <= hi[q]))))
+        assert got == want == set(map(tuple, ref[q].tolist())), q
+    R.close()
+    for ch in chunks:
+        ch.close()
+    enc.close()
+    buf.free()

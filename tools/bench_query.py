@@ -87,6 +87,9 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
     chunks = enc.open_chunks()  # (returns when the device is done: the call synchronises)
     open_s = time.perf_counter() - t0
     raster.free()  # the queries run against the encoded chunks alone
+    from dcdf_amd.raster import EncodedRaster
+    ER = EncodedRaster((TT, extent, extent), chunks)
+    nat_f_wall = nat_s_wall = nat_f_ms = nat_s_ms = 0.0
     # per-instant byte ranges of every chunk (host metadata) -> the touched encoded bytes of a sub-query
     ioff, isnap, base = [], [], [0]
     for c in chunks:
@@ -168,6 +171,22 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
         if len(cpu_f) < cpu_sample:
             cpu_f += [tuple(int(x) for x in sub[k, 1:8]) for k in range(min(m, cpu_sample - len(cpu_f)))]
         dev.free()
+        # the same dataset-level cubes through dcdf_raster_fill_window_batch: the split into pieces happens in the library
+        w0 = time.perf_counter()
+        dcub = np.ascontiguousarray(np.stack(spec[:6], axis=1).astype(np.uint32))
+        dvol = ((dcub[:, 1].astype(np.int64) - dcub[:, 0]) * (dcub[:, 3].astype(np.int64) - dcub[:, 2]) * (dcub[:, 5].astype(np.int64) - dcub[:, 4]))
+        doff = np.concatenate([[0], np.cumsum(dvol)[:-1]]).astype(np.uint64)
+        assert int(dvol.sum()) == total
+        dev = DeviceBuffer(max(4, total * 4))
+        nat_f_ms += ER.fill_windows_flat(dcub, dtype=np.int32, out_device_ptr=dev.ptr, out_offset=doff)
+        nat_f_wall += time.perf_counter() - w0
+        if check:
+            outn = dev.read(0, total * 4, np.int32)
+            for q in rng.integers(0, half, check):
+                ref, _ = brute(q, spec)
+                assert (outn[int(doff[q]):int(doff[q]) + ref.size].reshape(ref.shape) == ref).all(), "raster fill_window mismatch"
+                checked += 1
+        dev.free()
         # ---- search_window half: [lower, upper] = a random 10-percentile-wide band of the value range ----
         w0 = time.perf_counter()
         spec, sub = make_queries(rng, n - half, TT, extent, nt)
@@ -210,6 +229,21 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
         if len(cpu_s) < cpu_sample:
             cpu_s += [tuple(int(x) for x in sub[k, 1:8]) + (int(lower[k]), int(upper[k])) for k in range(min(m, cpu_sample - len(cpu_s)))]
         dtrip.free()
+        w0 = time.perf_counter()
+        dcub = np.ascontiguousarray(np.stack(spec[:6], axis=1).astype(np.uint32))
+        dtrip = DeviceBuffer(max(12, total * 12))
+        _, noff, ncnt, ms_n = ER.search_flat(dcub, qlo[:, 0], qlo[:, 1], out_device_ptr=dtrip.ptr, cap=total)
+        nat_s_ms += ms_n
+        nat_s_wall += time.perf_counter() - w0
+        assert int(ncnt.sum()) == int(counts.sum())
+        if check:
+            trip = dtrip.read(0, int(ncnt.sum()) * 12, np.uint32).reshape(-1, 3).astype(np.int64)
+            for q in rng.integers(0, n - half, check):
+                ref, (t0_, r0, c0) = brute(q, spec)
+                want = set(map(tuple, (np.argwhere((ref >= qlo[q, 0]) & (ref <= qlo[q, 1])) + np.array([t0_, r0, c0])).tolist()))
+                assert set(map(tuple, trip[int(noff[q]):int(noff[q]) + int(ncnt[q])].tolist())) == want, "raster search mismatch"
+                checked += 1
+        dtrip.free()
         if verbose:
             print("batch %d done" % b0, file=sys.stderr)
 
@@ -245,7 +279,11 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
         "end_to_end": {"fill_window_queries_per_s_device_result": nqf / fw_wall,
                        "fill_window_queries_per_s_host_result_int32": (nqf / fw_wall_host) if host_results and fw_wall_host else None,
                        "search_queries_per_s_device_result": nqs / se_wall,
-                       "note": "host routing (numpy) + handle arrays + the call; device result: nothing but counts crosses PCIe"},
+                       "note": "host routing (numpy) + handle arrays + the call; device result: nothing but counts crosses PCIe",
+                       "raster_level": {"entry": "dcdf_raster_fill_window_batch / dcdf_raster_search_batch (dataset-level cubes; the split into "
+                                                 "chunk-level pieces and the placement of every piece happen in the library)",
+                                        "fill_window_queries_per_s_device_result": nqf / nat_f_wall, "fill_window_kernel_ms": nat_f_ms,
+                                        "search_queries_per_s_device_result": nqs / nat_s_wall, "search_kernel_ms": nat_s_ms}},
     }
     # ---- CPU baseline: the oracle's Chunk::fill_window / iter_search on the sampled sub-queries --------------------------------
     if cpu_sample:
@@ -282,6 +320,7 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
                               "all_cores": {"cores": nthr, "value": len(cpu_s) * rsn / tsn, "hits_per_s": wsn / tsn, "seconds": tsn}},
             "gpu_subqueries_per_s_kernel": {"fill_window": nsub_f / (fw_ms * 1e-3), "search_window": nsub_s / (se_ms * 1e-3)},
         }
+    ER.close()
     for c in chunks:
         c.close()
     enc.close()
