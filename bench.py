@@ -369,6 +369,22 @@ def main():
                       "value": hcells / best, "unit": "cells/s", "input_GB_per_s": hcells * esz / best / 1e9,
                       "sample": "first %d chunks of this workload, best of 3 (%.3f s)" % (len(hs), best)}
 
+    # ---- "also report against a measured device-to-device copy on the same GPU" ------------------------------
+    copy_gbs = None
+    if rank == 0 and world == 1:
+        nb = 1 << 31
+        a = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        b = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        a.copy_(b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            a.copy_(b)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9  # bytes read + bytes written
+        del a, b
+
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
         alg_bytes = cells_local * esz + out_bytes  # every input cell read once, every output byte written once
@@ -408,7 +424,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_profile": traffic_src,
                          "kernel": "k2r::k_encode<%d,false,%d>" % (S.bit_length() - 1, {"i32": 1, "f32": 2, "i64": 3, "f64": 4}[args.dtype]),
                          "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes, "scope": "rank 0's GPU, HIP events around the encode kernel",
-                         "source_sha": source_sha()},
+                         "source_sha": source_sha(),
+                         "measured_copy": None if copy_gbs is None else
+                         {"GB/s": copy_gbs, "frac_of_copy": achieved / copy_gbs,
+                          "what": "device-to-device copy of 2 GiB on this GPU, bytes read + written per second"}},
             "cpu_baseline": cpu,
             "end_to_end_host_buffers": end_to_end,
             "gather": gather,
