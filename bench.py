@@ -224,6 +224,18 @@ def main():
         flat = flat2
         code = L.DCDF_F32 if args.dtype == "f32" else L.DCDF_F64
 
+    # diagnostics (config1 only): DCDF_BENCH_SAME=copy -> every chunk holds chunk 0's cells (equal work per chunk, still streamed
+    # from HBM); =alias -> every descriptor points AT chunk 0 (the same work served by the caches): their difference is what the
+    # memory system costs the kernel
+    same = os.environ.get("DCDF_BENCH_SAME")
+    if same and args.workload == "config1":
+        if same == "copy":
+            for d in data[1:]:
+                d.copy_(data[0])
+        else:
+            data = [data[0]] * len(data)
+        torch.cuda.synchronize()
+        workload += "; DCDF_BENCH_SAME=" + same
     descs = [(d.data_ptr(), code, (S * S, S, 1), tuple(d.shape), fb, 0) for d in data]
     enc = Encoder(descs, k=2)
     cells_local = sum(d.numel() for d in data)
