@@ -49,27 +49,14 @@ static uint32_t sidelen_log2(uint32_t rows, uint32_t cols) {  // snapshot.rs:118
 }
 static size_t elem_size(int dtype) { return (dtype == DCDF_I32 || dtype == DCDF_F32) ? 4 : 8; }
 
-// ---- speculative halves: which tiles of a class to encode as two work items --------------------------------------------
+// ---- speculative parts: which tiles of a class to encode as several work items ---------------------------------------------
 // A chunk is the unit of work (its instants are sequential) and a workgroup owns a CU, so when a GPU holds only a few
-// chunks per CU the last round of the work queue leaves CUs idle: 384 chunks on 256 CUs take two chunk-times, not 1.5.
-// Encoding the chunks at the END of the (longest-first) queue as two halves each fills that round.  The decision is a
-// simulation of the queue: `inst` = instants per tile in queue order, `wgs` = resident workgroups; candidates: no split, the
-// last (n mod wgs) tiles, all tiles; a split has to beat the unsplit makespan by 8 % (it costs one priming pass per second
-// half and the splice).  K2R_SPLIT=0 disables, K2R_SPLIT=all forces every tile (tests).
-static uint64_t queue_makespan(const std::vector<uint32_t>& cost, uint32_t wgs) {
-    std::vector<uint32_t> c(cost);
-    std::stable_sort(c.begin(), c.end(), [](uint32_t a, uint32_t b) { return a > b; });
-    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> free_at;
-    for (uint32_t w = 0; w < wgs; w++) free_at.push(0);
-    uint64_t end = 0;
-    for (uint32_t x : c) {
-        const uint64_t t = free_at.top() + x;
-        free_at.pop();
-        free_at.push(t);
-        end = std::max(end, t);
-    }
-    return end;
-}
+// chunks per CU the end of the work queue leaves CUs idle: 384 chunks on 256 CUs take two chunk-times, not 1.5, and whatever
+// the count, the last chunk popped runs a whole chunk-time after the queue is empty.  Encoding the chunks at the END of the
+// (longest-first) queue in parts of decreasing length (T/2, T/4, T/8, T/8: guided self-scheduling) fills that tail with
+// small items.  A part costs its instants plus a little (the wait for the first part's snapshot copy, the splice), and a
+// failed speculation costs a whole re-encode, so only tiles of the last rounds are split, and only when the queue is short:
+// n <= 4 * wgs.  K2R_SPLIT=0 disables, =all forces every tile (tests), =tail forces the last two rounds whatever n.
 static size_t plan_split(const std::vector<uint32_t>& inst, uint32_t wgs) {
     const size_t n = inst.size();
     const char* env = std::getenv("K2R_SPLIT");
@@ -81,66 +68,82 @@ static size_t plan_split(const std::vector<uint32_t>& inst, uint32_t wgs) {
     };
     if (env && std::strcmp(env, "0") == 0) return 0;
     if (env && std::strcmp(env, "all") == 0) return splittable(n);
-    auto makespan = [&](size_t ns) {
-        std::vector<uint32_t> cost;
-        for (size_t q = 0; q < n; q++) {
-            if (q + ns < n) cost.push_back(inst[q]);
-            else {
-                cost.push_back(inst[q] / 2);
-                cost.push_back(inst[q] - inst[q] / 2 + 1);
-            }
-        }
-        return queue_makespan(cost, wgs);
-    };
-    const uint64_t base = makespan(0);
-    size_t best = 0;
-    uint64_t best_t = base;
-    for (size_t cand : {n % wgs, n}) {
-        const size_t ns = splittable(cand);
-        if (ns == 0) continue;
-        const uint64_t t = makespan(ns);
-        if (t < best_t) {
-            best_t = t;
-            best = ns;
-        }
+    const size_t tail = std::min<size_t>(n, 2 * (size_t)wgs);
+    if (env && std::strcmp(env, "tail") == 0) return splittable(tail);
+    if (n > 4 * (size_t)wgs) return 0;
+    return splittable(tail);
+}
+// the instants at which the parts of a T-instant tile begin (after 0): T/2, then half of what is left, ... (<= 4 parts)
+static std::vector<uint32_t> part_bounds(uint32_t T) {
+    std::vector<uint32_t> b;
+    const char* env = std::getenv("K2R_PARTS");
+    const uint32_t maxp = env ? (uint32_t)std::max(2, std::min(8, std::atoi(env))) : 4u;
+    uint32_t at = 0, left = T;
+    while (b.size() + 2 <= maxp && left >= 4) {
+        at += (left + 1) / 2;
+        left -= (left + 1) / 2;
+        b.push_back(at);
     }
-    return (best_t * 100 <= base * 92) ? best : 0;
+    return b;
 }
 
-// Splices the two halves of a split tile: pairs[2 j] = the tile (first half, in its own slot), pairs[2 j + 1] = the
-// continuation's item.  Valid when the first half holds exactly one block (what the continuation assumed): its bytes are
-// appended, block 0's count byte (chunk offset 6, block.rs:89) and n_blocks (chunk.rs:238) are patched, the counters added.
-// Otherwise ST_RESPLIT (the host re-encodes the tile whole); an error of either half is the tile's error.
-__global__ void __launch_bounds__(1024) k_stitch(const uint32_t* __restrict__ pairs, const TileArgs* __restrict__ args,
-                                                  TileResult* __restrict__ res) {
-    const uint32_t a = pairs[2 * blockIdx.x], b = pairs[2 * blockIdx.x + 1];
-    const int32_t sa = res[a].status, sb = res[b].status;
-    const uint64_t la = res[a].len, lb = res[b].len;
-    int32_t st = ST_OK;
-    if (sa != ST_OK) st = sa;
-    else if (res[a].snapshots != 1) st = ST_RESPLIT;
-    else if (sb != ST_OK) st = sb;
-    else if (la + lb > args[a].out_cap) st = ST_OUT_CAPACITY;
+// Splices the parts of a split tile: items[first[j]] = the tile (first part, in its own slot), the rest = its continuations
+// in order.  Valid when the first part holds exactly one block and no middle part opened one (what every continuation
+// assumed): the bytes are appended, block 0's count byte (chunk offset 6, block.rs:89) and n_blocks (chunk.rs:238) are
+// patched, the counters added.  Otherwise ST_RESPLIT (the host re-encodes the tile whole); an error of any part is the
+// tile's error.
+constexpr int kMaxParts = 8;
+__global__ void __launch_bounds__(1024) k_stitch(const uint32_t* __restrict__ first, const uint32_t* __restrict__ items,
+                                                  const TileArgs* __restrict__ args, TileResult* __restrict__ res) {
+    __shared__ int32_t s_st;
+    __shared__ uint64_t s_at[kMaxParts + 1];
+    const uint32_t i0 = first[blockIdx.x], np = first[blockIdx.x + 1] - i0;
+    const uint32_t a = items[i0];
+    if (threadIdx.x == 0) {
+        int32_t st = ST_OK;
+        uint64_t total = res[a].len;
+        if (res[a].status != ST_OK) st = res[a].status;
+        else if (res[a].snapshots != 1) st = ST_RESPLIT;
+        for (uint32_t p = 1; p < np && st == ST_OK; p++) {
+            const uint32_t b = items[i0 + p];
+            if (res[b].status != ST_OK) st = res[b].status;
+            else if (p + 1 < np && res[b].snapshots != 0) st = ST_RESPLIT;
+            s_at[p] = total;
+            total += res[b].len;
+        }
+        if (st == ST_OK && total > args[a].out_cap) st = ST_OUT_CAPACITY;
+        s_at[np] = total;
+        s_st = st;
+    }
+    __syncthreads();
+    const int32_t st = s_st;
     if (st == ST_OK) {
-        uint8_t* dst = args[a].out + la;
-        const uint8_t* src = args[b].out;
-        // 16 bytes per thread and step (the source slot is 256-byte aligned; the destination is wherever the first half ended:
+        // 16 bytes per thread and step (a source slot is 256-byte aligned; the destination is wherever the previous part ended:
         // global memory takes unaligned vector stores), then the tail
         typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
         typedef uint32_t u4a __attribute__((ext_vector_type(4)));
-        const uint64_t nv = lb / 16;
-        for (uint64_t i = threadIdx.x; i < nv; i += blockDim.x) *(u4*)(dst + 16 * i) = *(const u4a*)(src + 16 * i);
-        for (uint64_t i = 16 * nv + threadIdx.x; i < lb; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t p = 1; p < np; p++) {
+            const uint32_t b = items[i0 + p];
+            uint8_t* dst = args[a].out + s_at[p];
+            const uint8_t* src = args[b].out;
+            const uint64_t lb = s_at[p + 1] - s_at[p], nv = lb / 16;
+            for (uint64_t i = threadIdx.x; i < nv; i += blockDim.x) *(u4*)(dst + 16 * i) = *(const u4a*)(src + 16 * i);
+            for (uint64_t i = 16 * nv + threadIdx.x; i < lb; i += blockDim.x) dst[i] = src[i];
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (st == ST_OK) {
-            args[a].out[6] = (uint8_t)res[b].carry_count;
-            store_be32(args[a].out + 2, 1u + res[b].snapshots);
-            res[a].len = la + lb;
-            res[a].snapshots += res[b].snapshots;
-            res[a].logs += res[b].logs;
-            res[a].stash_logs += res[b].stash_logs;
+            const uint32_t last = items[i0 + np - 1];
+            args[a].out[6] = (uint8_t)res[last].carry_count;
+            store_be32(args[a].out + 2, 1u + res[last].snapshots);
+            res[a].len = s_at[np];
+            for (uint32_t p = 1; p < np; p++) {
+                const uint32_t b = items[i0 + p];
+                res[a].snapshots += res[b].snapshots;
+                res[a].logs += res[b].logs;
+                res[a].stash_logs += res[b].stash_logs;
+            }
         } else {
             res[a].status = st;
             res[a].len = 0;
@@ -170,11 +173,11 @@ struct dcdf_encoder {
     std::vector<size_t> lists_off;     // per class offset (u64 words) into d_lists
     std::vector<uint32_t> grid;
     std::vector<std::unique_ptr<DevBuf>> retry_slots;  // bigger slots for tiles that overflowed
-    // Speculative halves (k2r_encode.h): tiles encoded as two work items, (a) the tile's own TileArgs restricted to the first
-    // instants and (b) an extra TileArgs at index n + j for the rest, spliced by k_stitch inside the timed region.
+    // Speculative parts (k2r_encode.h): tiles encoded as several work items, the tile's own TileArgs restricted to the first
+    // instants and extra TileArgs at indices >= n for the rest, spliced by k_stitch inside the timed region.
     std::vector<std::vector<uint32_t>> class_items;  // per class: the launch order (tile indices and extra indices >= n)
-    std::vector<uint32_t> split_a, split_b;          // pairs (tile, extra item)
-    DevBuf d_pairs, d_out_b;
+    std::vector<std::vector<uint32_t>> split;        // per split tile: {tile, continuation items in order}
+    DevBuf d_part_first, d_part_items, d_out_b, d_flags, d_shared;
     // tiles outside the fused kernel's contract (k != 2, sidelen < 8 or > 256): encoded by the universal kernel
     // (k2r_generic.hip); key = k << 8 | H
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> generic_groups;
@@ -301,10 +304,10 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
         a.minmax = e->d_minmax.as<int64_t>() + e->minmax_off[i];
         e->args[i] = a;
     }
-    // per-class launch geometry; which tiles are encoded as two speculative halves (plan_split)
+    // per-class launch geometry; which tiles are encoded in speculative parts (plan_split)
     size_t order_total = 0, lists_total = 0;
-    uint64_t out_b_total = 0;
-    std::vector<uint64_t> out_b_off;
+    uint64_t out_b_total = 0, shared_total = 0;
+    std::vector<uint64_t> out_b_off, shared_off;
     e->class_items.resize(e->classes.size());
     for (size_t ci = 0; ci < e->classes.size(); ci++) {
         const EncClass& c = e->classes[ci];
@@ -317,29 +320,40 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
         std::vector<uint32_t> inst(v.size());
         for (size_t q = 0; q < v.size(); q++) inst[q] = tiles[v[q]].instants;
         const size_t ns = plan_split(inst, std::max(1u, wgs));  // the LAST ns tiles of v are split
-        struct Item { uint32_t idx, cost; };
+        struct Item { uint32_t idx, cost, cont; };
         std::vector<Item> items;
+        const uint64_t cmp_bytes = ((2ull << (2 * c.log2s)) + 255) & ~255ull;  // 2 bytes per cell of the padded tile
         for (size_t q = 0; q < v.size(); q++) {
             const uint32_t ti = v[q], T = tiles[ti].instants;
             if (q + ns < v.size()) {
-                items.push_back({ti, T});
+                items.push_back({ti, T, 0});
                 continue;
             }
-            const uint32_t m = T / 2, bi = (uint32_t)e->args.size();
-            e->args[ti].inst_end = m;
-            TileArgs b = e->args[ti];
-            b.inst_begin = m;
-            b.inst_end = T;
-            b.out_cap = ((e->slot_cap[ti] * (T - m) + T - 1) / T + 4096 + 255) & ~255ull;
-            out_b_off.push_back(out_b_total);
-            out_b_total += b.out_cap;
-            e->args.push_back(b);
-            e->split_a.push_back(ti);
-            e->split_b.push_back(bi);
-            items.push_back({ti, m});
-            items.push_back({bi, T - m + 1});  // + the priming pass
+            const std::vector<uint32_t> at = part_bounds(T);
+            std::vector<uint32_t> parts{ti};
+            e->args[ti].inst_end = at[0];
+            items.push_back({ti, at[0], 0});
+            uint32_t prev_cost = at[0];
+            shared_off.push_back(shared_total);
+            shared_total += cmp_bytes;
+            for (size_t p = 0; p < at.size(); p++) {
+                const uint32_t m0 = at[p], m1 = p + 1 < at.size() ? at[p + 1] : T, bi = (uint32_t)e->args.size();
+                TileArgs b = e->args[ti];
+                b.inst_begin = m0;
+                b.inst_end = m1;
+                b.out_cap = ((e->slot_cap[ti] * (m1 - m0) + T - 1) / T + 4096 + 255) & ~255ull;
+                out_b_off.push_back(out_b_total);
+                out_b_total += b.out_cap;
+                e->args.push_back(b);
+                parts.push_back(bi);
+                prev_cost = std::min(prev_cost, m1 - m0);  // (never sorted before the part it follows)
+                items.push_back({bi, prev_cost, 1});
+            }
+            e->split.push_back(std::move(parts));
         }
-        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+        // longest first; at equal length a first part before any continuation -- with first parts at least as long as their
+        // continuations, every continuation is popped after the part it waits for (k2r_encode.h)
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost != b.cost ? a.cost > b.cost : a.cont < b.cont; });
         for (const Item& it : items) e->class_items[ci].push_back(it.idx);
         const uint32_t g = (uint32_t)std::min<uint64_t>(items.size(), wgs);
         e->grid.push_back(std::max(1u, g));
@@ -348,16 +362,27 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
         e->lists_off.push_back(lists_total);
         lists_total += (size_t)e->grid.back() * encode_list_words(c);
     }
-    if (!e->split_a.empty()) {
+    if (!e->split.empty()) {
         K2R_HIP(e->d_out_b.alloc(out_b_total));
-        std::vector<uint32_t> pairs;
-        for (size_t j = 0; j < e->split_a.size(); j++) {
-            e->args[e->split_b[j]].out = e->d_out_b.as<uint8_t>() + out_b_off[j];
-            pairs.push_back(e->split_a[j]);
-            pairs.push_back(e->split_b[j]);
+        K2R_HIP(e->d_shared.alloc(shared_total));
+        K2R_HIP(e->d_flags.alloc(e->split.size() * 16));
+        std::vector<uint32_t> first{0}, flat;
+        size_t nb = 0;
+        for (size_t j = 0; j < e->split.size(); j++) {
+            const auto& parts = e->split[j];
+            for (size_t p = 0; p < parts.size(); p++) {
+                TileArgs& a = e->args[parts[p]];
+                a.shared_flag = e->d_flags.as<uint32_t>() + 4 * j;
+                a.shared_cmp = (uint32_t*)(e->d_shared.as<uint8_t>() + shared_off[j]);
+                if (p > 0) a.out = e->d_out_b.as<uint8_t>() + out_b_off[nb++];
+                flat.push_back(parts[p]);
+            }
+            first.push_back((uint32_t)flat.size());
         }
-        K2R_HIP(e->d_pairs.alloc(pairs.size() * 4));
-        K2R_HIP(hipMemcpy(e->d_pairs.p, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+        K2R_HIP(e->d_part_first.alloc(first.size() * 4));
+        K2R_HIP(e->d_part_items.alloc(flat.size() * 4));
+        K2R_HIP(hipMemcpy(e->d_part_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+        K2R_HIP(hipMemcpy(e->d_part_items.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
         // the item tables grew
         e->d_args.release();
         e->d_results.release();
@@ -378,6 +403,7 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
 static int run_classes(dcdf_encoder* e, const std::vector<std::vector<uint32_t>>* subset, float* kernel_ms) {
     // subset == nullptr: all tiles of every class (order already on the device)
     K2R_HIP(hipMemsetAsync(e->d_queue.p, 0, e->d_queue.bytes, e->stream));
+    if (!subset && !e->split.empty()) K2R_HIP(hipMemsetAsync(e->d_flags.p, 0, e->d_flags.bytes, e->stream));
     K2R_HIP(hipEventRecord(e->ev0, e->stream));
     for (size_t ci = 0; ci < e->classes.size(); ci++) {
         uint32_t nt = (uint32_t)e->class_items[ci].size();
@@ -397,9 +423,9 @@ static int run_classes(dcdf_encoder* e, const std::vector<std::vector<uint32_t>>
         L.grid = std::min(e->grid[ci], std::max(1u, nt));
         K2R_HIP(launch_encode(e->classes[ci], L, e->stream));
     }
-    if (!subset && !e->split_a.empty())  // splice the speculative halves (inside the timed region)
-        hipLaunchKernelGGL(k2r::k_stitch, dim3((uint32_t)e->split_a.size()), dim3(1024), 0, e->stream, e->d_pairs.as<uint32_t>(),
-                           e->d_args.as<TileArgs>(), e->d_results.as<TileResult>());
+    if (!subset && !e->split.empty())  // splice the speculative parts (inside the timed region)
+        hipLaunchKernelGGL(k2r::k_stitch, dim3((uint32_t)e->split.size()), dim3(1024), 0, e->stream, e->d_part_first.as<uint32_t>(),
+                           e->d_part_items.as<uint32_t>(), e->d_args.as<TileArgs>(), e->d_results.as<TileResult>());
     K2R_HIP(hipEventRecord(e->ev1, e->stream));
     K2R_HIP(hipStreamSynchronize(e->stream));
     if (kernel_ms) K2R_HIP(hipEventElapsedTime(kernel_ms, e->ev0, e->ev1));
@@ -522,6 +548,8 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
                 // half, or a slot too small, would come back on every run)
                 const bool was_split = e->args[ti].inst_end != 0;
                 e->args[ti].inst_end = 0;
+                e->args[ti].shared_flag = nullptr;
+                e->args[ti].shared_cmp = nullptr;
                 unsplit = unsplit || was_split;
                 K2R_HIP(hipMemcpy(e->d_args.as<TileArgs>() + ti, &e->args[ti], sizeof(TileArgs), hipMemcpyHostToDevice));
                 again[ci].push_back(ti);
@@ -531,22 +559,24 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
         rc = run_classes(e, &again, nullptr);
         if (rc != DCDF_OK) return rc;
         K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
-        if (unsplit) {  // drop the pairs (and extra items) of the tiles that are whole from now on
-            std::vector<uint32_t> pairs, sa, sb;
+        if (unsplit) {  // drop the parts (extra items) of the tiles that are whole from now on
+            std::vector<std::vector<uint32_t>> keep_split;
             std::vector<uint8_t> gone(e->args.size(), 0);
-            for (size_t j = 0; j < e->split_a.size(); j++) {
-                if (e->args[e->split_a[j]].inst_end == 0) {
-                    gone[e->split_b[j]] = 1;
+            std::vector<uint32_t> first{0}, flat;
+            for (auto& parts : e->split) {
+                if (e->args[parts[0]].inst_end == 0) {
+                    for (size_t p = 1; p < parts.size(); p++) gone[parts[p]] = 1;
                     continue;
                 }
-                sa.push_back(e->split_a[j]);
-                sb.push_back(e->split_b[j]);
-                pairs.push_back(e->split_a[j]);
-                pairs.push_back(e->split_b[j]);
+                for (uint32_t it : parts) flat.push_back(it);
+                first.push_back((uint32_t)flat.size());
+                keep_split.push_back(std::move(parts));
             }
-            e->split_a.swap(sa);
-            e->split_b.swap(sb);
-            if (!pairs.empty()) K2R_HIP(hipMemcpy(e->d_pairs.p, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+            e->split.swap(keep_split);
+            if (!flat.empty()) {
+                K2R_HIP(hipMemcpy(e->d_part_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+                K2R_HIP(hipMemcpy(e->d_part_items.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+            }
             for (auto& items : e->class_items) {
                 std::vector<uint32_t> keep;
                 for (uint32_t it : items)

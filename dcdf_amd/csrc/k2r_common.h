@@ -52,13 +52,19 @@ struct TileArgs {  // one Chunk::build input (device-visible copy of dcdf_tile_d
     uint64_t out_cap;  // bytes
     int64_t* minmax;   // [instants][2] or null
     uint32_t stash_words;  // 0 = default; else caps the LDS words the log stash may use (k2r_encode.h; tests, A/B runs)
-    // Part of a chunk (k2r_encode.h "speculative halves"): instants [inst_begin, inst_end) only; inst_end == 0 means all.
+    // Part of a chunk (k2r_encode.h "speculative parts"): instants [inst_begin, inst_end) only; inst_end == 0 means all.
     // inst_begin > 0 = a continuation: it assumes the chunk's first block is still open at inst_begin, with instant 0 as its
     // snapshot and inst_begin instants in it, and writes its Logs / Blocks from byte 0 of `out` (no chunk header).
     uint32_t inst_begin;
     uint32_t inst_end;
     uint32_t _reserved;
+    // A chunk encoded in parts shares instant 0's compact snapshot copy: the part that starts at instant 0 writes it to
+    // shared_cmp and sets shared_flag[0] (1 = copy valid, 2 = no compact copy: range beyond 16 bits, 3 = gave up), with the
+    // copy's base value in shared_flag[1]; continuations wait for the flag.  Both null for a chunk encoded whole.
+    uint32_t* shared_flag;
+    uint32_t* shared_cmp;
 };
+constexpr uint32_t PART_CMP = 1, PART_NOCMP = 2, PART_FAILED = 3;
 
 constexpr int NPROF = 20;
 struct TileResult {

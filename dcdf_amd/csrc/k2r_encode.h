@@ -982,15 +982,20 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         return inval(br << h, bc << h);
     };
 
-    // Speculative halves (near-linear scaling when a GPU holds few chunks per CU): a chunk's instants may be encoded by two
-    // work items.  The first, [0, m), is an ordinary encode of those instants.  The second, [m, T), is a CONTINUATION: it
-    // assumes what holds for 31 instants in 32 on the benchmark's data -- that no block boundary falls into [1, m), so that
-    // instant 0 is still the open block's snapshot and the block holds m instants -- and starts from there: it first rebuilds
-    // instant 0's extremes and compact copy ("priming", one analysis-only pass), then runs chunk.rs:55-74 from instant m on,
-    // writing its Logs and Blocks from byte 0 of its own slot.  stitch_halves() checks the assumption against the first
-    // half's result (exactly one snapshot) and splices the bytes; otherwise the chunk is re-encoded whole.
+    // Speculative parts (near-linear scaling when a GPU holds few chunks per CU): a chunk's instants may be encoded by several
+    // work items.  The first, [0, m), is an ordinary encode of those instants -- except that it leaves instant 0's compact
+    // snapshot copy in a buffer of the CHUNK (ta.shared_cmp) instead of this workgroup's scratch, and says so (ta.shared_flag).
+    // Every other part, [m, m'), is a CONTINUATION: it assumes what holds for 31 instants in 32 on the benchmark's data -- that
+    // no block boundary falls into [1, m), so that instant 0 is still the open block's snapshot and the block holds m instants
+    // -- waits for that copy, and runs chunk.rs:55-74 from instant m on, writing its Logs and Blocks from byte 0 of its own
+    // slot.  k_stitch checks the assumption against the earlier parts' results (one snapshot in the first, none in the
+    // middle ones) and splices the bytes; otherwise the chunk is re-encoded whole.  The work queue holds every first part
+    // before any continuation, so a continuation's wait is for a workgroup that is already running.
     const uint32_t i_begin = ta.inst_begin, i_end = ta.inst_end != 0 ? ta.inst_end : ta.instants;
     const bool cont = i_begin > 0;
+    const bool head = !cont && ta.shared_flag != nullptr;  // the first of several parts
+    bool published = false;
+    uint32_t* cmp = scmp;  // where the open block's compact snapshot copy lives
     constexpr uint32_t NO_HDR = 0xffffffffu;  // the open block's count byte lives in the first half's bytes
     uint32_t carry = 0;
     uint32_t off = cont ? 0u : 6u;            // chunk header: encoding, fractional_bits, n_blocks (chunk.rs:236-238)
@@ -1035,15 +1040,26 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             for (int j = 0; j < 4; j++) {
                 int32_t t16[16];
                 load_sub16<PADDED, VEC>(ta, from, r0, c0, j, t16, lerr);
-                store_compact<C>(scmp, tid, j, s_base, t16);
+                store_compact<C>(cmp, tid, j, s_base, t16);
             }
         });
         ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
     };
 
-    for (uint32_t it = cont ? i_begin - 1 : 0u; it < i_end && status == ST_OK; it++) {
-        const bool priming = cont && it + 1 == i_begin;  // a continuation's first pass: instant 0, analysis only
-        const uint32_t inst = priming ? 0u : it;
+    if (cont) {  // the open block as the first part left it: instant 0 is its snapshot
+        const uint32_t f = ex.await(ta.shared_flag, PART_FAILED);
+        if (f == PART_FAILED) status = ST_RESPLIT;
+        s_cmp = f == PART_CMP;
+        s_base = (int32_t)ex.flag_payload(ta.shared_flag);
+        s_idx = 0;
+        blk_count = i_begin;
+        cmp = ta.shared_cmp;
+        ex.par([&](int tid, EncRegs&) {
+            if (tid == 0) sh.err = 0;
+        });
+    }
+
+    for (uint32_t inst = i_begin; inst < i_end && status == ST_OK; inst++) {
         const bool have_s = inst > 0;
         // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
         // Nothing but four per-height-2 summaries survives this phase in registers: cells are re-read on
@@ -1092,7 +1108,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 // ---- log candidate vs. the open block's snapshot (log.rs:112-165, 725-817) ----
                 if (have_s) {
                     int32_t s16[16];
-                    if (s_cmp) load_compact<C>(scmp, tid, j, s_base, s16);
+                    if (s_cmp) load_compact<C>(cmp, tid, j, s_base, s16);
                     else load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
                     int32_t smn1[4], smx1[4], df1[4];
                     bool eq1[4];
@@ -1235,15 +1251,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             });
         }
 
-        if (priming) {  // instant 0 as the open block's snapshot: its extremes decide the compact copy (as in the as_snapshot branch)
-            const int32_t rmin = ex.uni(sh.tmin[C::top_off(H)]), rmax = ex.uni(sh.tmax[C::top_off(H)]);
-            s_cmp = (int64_t)rmax - (int64_t)rmin <= 65535;
-            s_base = rmin;
-            s_idx = 0;
-            blk_count = i_begin;
-            if (s_cmp) compact_pass(0);
-            continue;
-        }
         ex.stamp(1);  // phase 2: top of the tree
         // node predicates on the top arrays (index = top_off(h) + j)
         auto PS = [&](int h, uint32_t j) -> bool {
@@ -1620,6 +1627,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             const int32_t rmin = ex.uni(sh.tmin[C::top_off(H)]), rmax = ex.uni(sh.tmax[C::top_off(H)]);
             s_cmp = (int64_t)rmax - (int64_t)rmin <= 65535 && inst + 1 < ta.instants;
             s_base = rmin;
+            cmp = (head && inst == 0) ? ta.shared_cmp : scmp;
         } else {
             n_log++;
         }
@@ -1912,6 +1920,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             ex.stamp(9);
         } else {
             if (as_snapshot && s_cmp) compact_pass(inst);  // leave the compact copy of this snapshot instant for the logs that follow
+            if (head && inst == 0) {  // ... and for the parts that continue this chunk
+                ex.publish(ta.shared_flag, s_cmp ? PART_CMP : PART_NOCMP, (uint32_t)s_base);
+                published = true;
+            }
             passA(EmTag<EM_LIST>{});
             ex.barrier();  // pass B consumes the work list pass A built
             ex.stamp(10);  // emission pass A (own/top nodes, height-2 groups, work list)
@@ -2041,6 +2053,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         off += isize;
         blk_count++;
     }
+
+    if (head && !published) ex.publish(ta.shared_flag, PART_FAILED, 0u);  // (an error before instant 0 was emitted)
 
     // ---- close the last block, chunk header (chunk.rs:76-78, 238) ----
     ex.par([&](int tid, EncRegs&) {

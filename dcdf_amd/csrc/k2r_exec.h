@@ -34,6 +34,39 @@ struct GpuExec {
     __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
     __device__ __forceinline__ void barrier_global() { __syncthreads(); }
 
+    // Hand-off of global data to ANOTHER workgroup (the shared snapshot copy of a chunk encoded in parts, k2r_encode.h): the
+    // producer's waves have drained their stores (barrier_global), one lane writes the XCD's L2 back and sets the flag;
+    // the consumer polls the flag with one lane (agent scope), invalidates its CU's L1, and the workgroup joins at a barrier
+    // before any plain load of the data (MI355X_MICROARCH.md, inter-workgroup visibility).  The poll is bounded: a producer
+    // that never publishes (it cannot: every exit path does) would otherwise hang the queue.
+    __device__ __forceinline__ void publish(uint32_t* flag, uint32_t value, uint32_t payload) {
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(flag + 1, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __device__ __forceinline__ uint32_t await(const uint32_t* flag, uint32_t timeout_value) {
+        if (tid == 0) {
+            uint32_t v = 0;
+            for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+                v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v != 0) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            sh.err = v != 0 ? (int32_t)v : (int32_t)timeout_value;  // (sh.err is idle between instants; the caller resets it)
+        }
+        __syncthreads();
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane(sh.err);
+        __syncthreads();
+        return v;
+    }
+    __device__ __forceinline__ uint32_t flag_payload(const uint32_t* flag) {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+
     template <class F>
     __device__ __forceinline__ void par(F&& f) {
         f(tid, r);
@@ -248,6 +281,12 @@ struct SimExec {
     }
     void barrier() {}
     void barrier_global() {}
+    void publish(uint32_t* flag, uint32_t value, uint32_t payload) {
+        flag[1] = payload;
+        flag[0] = value;
+    }
+    uint32_t await(const uint32_t* flag, uint32_t timeout_value) { return flag[0] != 0 ? flag[0] : timeout_value; }  // (items run in queue order)
+    uint32_t flag_payload(const uint32_t* flag) { return flag[1]; }
     void stamp(int) {}
     template <class T>
     T uni(T v) const { return v; }

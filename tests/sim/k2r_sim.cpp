@@ -34,8 +34,11 @@ static void run_l(const TileArgs& ta, TileResult* res, bool padded, int vec) {
     else run<LOG2S, false, 0>(ta, res);
 }
 
-static uint32_t g_split_at = 0;  // > 0: encode as two speculative halves [0, m) + [m, T) and splice (mirrors k_stitch)
-extern "C" void sim_set_split(uint32_t m) { g_split_at = m; }
+// > 0: encode in speculative parts and splice (mirrors k_stitch): two parts [0, m) + [m, T), or g_parts parts of decreasing
+// length as k2r_capi_encode.hip's part_bounds cuts them
+static uint32_t g_split_at = 0, g_parts = 0;
+extern "C" void sim_set_split(uint32_t m) { g_split_at = m; g_parts = 0; }
+extern "C" void sim_set_parts(uint32_t p) { g_parts = p; g_split_at = 0; }
 
 static uint32_t g_last_stash_logs = 0;
 extern "C" uint32_t sim_last_stash_logs() { return g_last_stash_logs; }
@@ -72,30 +75,58 @@ extern "C" int sim_encode(const void* base, int dtype, int64_t st, int64_t sr, i
             case 8: run_l<8>(a, r, padded, vec); break;
         }
     };
-    if (g_split_at > 0 && g_split_at < instants) {
-        // the splice of k2r_capi_encode.hip's k_stitch, on the host
-        TileArgs a = ta, b = ta;
-        a.inst_end = g_split_at;
-        b.inst_begin = g_split_at;
-        b.inst_end = instants;
-        std::vector<uint8_t> outb(cap);
-        b.out = outb.data();
-        TileResult rb{};
-        run_lg(a, &res);
-        run_lg(b, &rb);
+    std::vector<uint32_t> at;  // where the parts after the first begin
+    if (g_split_at > 0 && g_split_at < instants) at.push_back(g_split_at);
+    if (g_parts >= 2) {
+        uint32_t pos = 0, left = instants;
+        while (at.size() + 2 <= g_parts && left >= 4) {
+            pos += (left + 1) / 2;
+            left -= (left + 1) / 2;
+            at.push_back(pos);
+        }
+    }
+    if (!at.empty()) {
+        // the parts in queue order (the first, then its continuations), then the splice of k_stitch on the host
+        std::vector<uint32_t> flag(4, 0), shared_cmp((size_t)S * S / 2 + 64, 0xA5A5A5A5u);
+        const size_t np = at.size() + 1;
+        std::vector<TileArgs> pa(np, ta);
+        std::vector<TileResult> pr(np);
+        std::vector<std::vector<uint8_t>> pout(np);
+        for (size_t p = 0; p < np; p++) {
+            pa[p].inst_begin = p == 0 ? 0 : at[p - 1];
+            pa[p].inst_end = p + 1 < np ? at[p] : instants;
+            pa[p].shared_flag = flag.data();
+            pa[p].shared_cmp = shared_cmp.data();
+            if (p > 0) {
+                pout[p].assign(cap, 0);
+                pa[p].out = pout[p].data();
+            }
+            pr[p] = TileResult{};
+            run_lg(pa[p], &pr[p]);
+        }
+        res = pr[0];
         int32_t st = ST_OK;
+        uint64_t total = res.len;
         if (res.status != ST_OK) st = res.status;
         else if (res.snapshots != 1) st = ST_RESPLIT;
-        else if (rb.status != ST_OK) st = rb.status;
-        else if (res.len + rb.len > cap) st = ST_OUT_CAPACITY;
+        for (size_t p = 1; p < np && st == ST_OK; p++) {
+            if (pr[p].status != ST_OK) st = pr[p].status;
+            else if (p + 1 < np && pr[p].snapshots != 0) st = ST_RESPLIT;
+            total += pr[p].len;
+        }
+        if (st == ST_OK && total > cap) st = ST_OUT_CAPACITY;
         if (st == ST_OK) {
-            std::memcpy(out + res.len, outb.data(), rb.len);
-            out[6] = (uint8_t)rb.carry_count;
-            store_be32(out + 2, 1u + rb.snapshots);
-            res.len += rb.len;
-            res.snapshots += rb.snapshots;
-            res.logs += rb.logs;
-            res.stash_logs += rb.stash_logs;
+            uint64_t o = res.len;
+            for (size_t p = 1; p < np; p++) {
+                std::memcpy(out + o, pout[p].data(), pr[p].len);
+                o += pr[p].len;
+                res.snapshots += pr[p].snapshots;
+                res.logs += pr[p].logs;
+                res.stash_logs += pr[p].stash_logs;
+            }
+            out[6] = (uint8_t)pr[np - 1].carry_count;
+            store_be32(out + 2, 1u + pr[np - 1].snapshots);
+            res.len = total;
         } else {
             res.status = st;
             res.len = 0;

@@ -257,13 +257,16 @@ def test_object_sha256_on_device(dc):
     assert r.returncode == 0 and "sha256 ok" in r.stdout, r.stdout + r.stderr
 
 
-def test_speculative_halves_splice(dc, monkeypatch):
-    """K2R_SPLIT=all: every tile is encoded as two work items ([0, T/2) and a continuation that assumes the first block is
-    still open) and spliced on the device by k_stitch.  Bytes, counters and per-instant (min, max) must equal the sequential
-    encode's -- including tiles whose first half closes a block (the assumption fails: re-encoded whole), padded tiles, other
-    element types and chunks too short to split."""
+@pytest.mark.parametrize("parts", ["2", "4", "8"])
+def test_speculative_parts_splice(dc, monkeypatch, parts):
+    """K2R_SPLIT=all: every tile is encoded as several work items ([0, T/2), then continuations of decreasing length that assume
+    the first block is still open and read instant 0's compact copy from the buffer the first part published) and spliced on
+    the device by k_stitch.  Bytes, counters and per-instant (min, max) must equal the sequential encode's -- including tiles
+    where a block closes early (the assumption fails: re-encoded whole), padded tiles, other element types and chunks too
+    short to split."""
     from dcdf_amd import synth
     monkeypatch.setenv("K2R_SPLIT", "all")
+    monkeypatch.setenv("K2R_PARTS", parts)
     arrays = [synth.cells(0xDCDF0003, 32 * s, 32 * s + 32, 256 * i, 256 * i + 256, 0, 256, np.int32) for s, i in [(0, 0), (1, 3), (2, 5)]]
     arrays.append(synth.cells(0xDCDF0003, 352, 365, 0, 256, 256, 512, np.int32))          # the 13-instant last segment
     arrays.append(synth.cells(0xDCDF0002, 0, 9, 0, 200, 0, 256, np.int32))                 # padded
@@ -275,6 +278,10 @@ def test_speculative_halves_splice(dc, monkeypatch):
     late[20:] = np.random.default_rng(6).integers(0, 1 << 20, size=late[20:].shape)       # block boundaries in the second half only
     arrays.append(late)
     arrays.append(arrays[2][:3].copy())                                                    # 3 instants: not split
+    wide = arrays[0].copy()
+    wide[0, 7, 7] = 300000                                                                 # instant 0 beyond 16 bits: no compact copy to share
+    arrays.append(wide)
+    arrays += [synth.cells(0xDCDF0003, 32 * s, 32 * s + 32, 0, 256, 256 * j, 256 * j + 256, np.int32) for s in range(3) for j in range(8)]
     assert_same(dc, arrays)
     f = (arrays[5][:, :64, :64] // 2 / 8.0).astype(np.float32)
     assert_same(dc, [f], fractional_bits=3)

@@ -279,6 +279,17 @@ def test_speculative_halves():
         for m in (1, 2, 4, 5, 8):
             L.sim_set_split(m)
             assert check(a)[0] == ref
+        for p in (2, 3, 4):                                                  # parts of decreasing length (k2r_capi_encode.hip part_bounds)
+            L.sim_set_parts(p)
+            assert check(a)[0] == ref
+            big = np.concatenate([a, a[::-1], a])                            # 27 instants: parts at 14, 21, 24
+            L.sim_set_parts(0)
+            one_block = S.encode(big)[2] == 1
+            L.sim_set_parts(p)
+            if one_block:
+                check(big)
+            else:
+                assert S.encode(big)[0] in (0, -102)
         L.sim_set_split(4)
         check(a[:, :50, :37])                                                # padded tile
         check(a.astype(np.int64) * 2 + 1)
@@ -294,6 +305,12 @@ def test_speculative_halves():
             assert S.encode(b)[1] == ref_b
         L.sim_set_split(7)                                                   # boundary at instant 6 < 7: the assumption fails
         assert S.encode(b)[0] == -102
+        L.sim_set_parts(4)                                                   # 9 instants: parts at 5, 7, 8 -- the last two assume too much
+        assert S.encode(b)[0] == -102
+        w = a.copy()                                                         # a snapshot beyond 16 bits: no compact copy to share
+        w[0, 0, 0] = 200000
+        L.sim_set_parts(3)
+        assert S.encode(w)[1] == O.chunk_build(w)
         c = array_n(16, T=12).astype(np.int64)                               # the reference fixture: blocks of 3 (a8 repeats)
         _, _, ns, _ = S.encode(c)
         L.sim_set_split(6)
@@ -304,6 +321,7 @@ def test_speculative_halves():
         assert S.encode(d)[0] == -8
     finally:
         L.sim_set_split(0)
+        L.sim_set_parts(0)
 
 
 def test_stash_overflow_goes_to_global_scratch():
