@@ -282,7 +282,7 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
     K2R_HIP(hipStreamCreate(&e->stream));
     K2R_HIP(hipEventCreate(&e->ev0));
     K2R_HIP(hipEventCreate(&e->ev1));
-    K2R_HIP(e->d_out.alloc(out_total));
+    K2R_HIP(e->d_out.alloc_pooled(out_total));
     K2R_HIP(e->d_minmax.alloc(mm_total * 8));
     K2R_HIP(e->d_args.alloc(n * sizeof(TileArgs)));
     K2R_HIP(e->d_results.alloc(n * sizeof(TileResult)));
@@ -363,8 +363,8 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
         lists_total += (size_t)e->grid.back() * encode_list_words(c);
     }
     if (!e->split.empty()) {
-        K2R_HIP(e->d_out_b.alloc(out_b_total));
-        K2R_HIP(e->d_shared.alloc(shared_total));
+        K2R_HIP(e->d_out_b.alloc_pooled(out_b_total));
+        K2R_HIP(e->d_shared.alloc_pooled(shared_total));
         K2R_HIP(e->d_flags.alloc(e->split.size() * 16));
         std::vector<uint32_t> first{0}, flat;
         size_t nb = 0;
@@ -391,7 +391,7 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
     }
     K2R_HIP(e->d_order.alloc(std::max<size_t>(order_total, 1) * 4));
     K2R_HIP(e->d_queue.alloc(std::max<size_t>(e->classes.size(), 1) * 4));
-    K2R_HIP(e->d_lists.alloc(std::max<size_t>(lists_total, 1) * 8));
+    K2R_HIP(e->d_lists.alloc_pooled(std::max<size_t>(lists_total, 1) * 8));
     for (size_t ci = 0; ci < e->classes.size(); ci++)
         K2R_HIP(hipMemcpy(e->d_order.as<uint32_t>() + e->order_off[ci], e->class_items[ci].data(), e->class_items[ci].size() * 4,
                           hipMemcpyHostToDevice));
@@ -724,7 +724,7 @@ extern "C" int dcdf_encoder_gather(dcdf_encoder* e, uint8_t* dst, size_t cap, ui
         K2R_HIP(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
         DevBuf d_items, d_packed;
         K2R_HIP(d_items.alloc(items.size() * sizeof(PackItem)));
-        K2R_HIP(d_packed.alloc(tot));
+        K2R_HIP(d_packed.alloc_pooled(tot));
         K2R_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice, own.s));
         const uint32_t grid = (uint32_t)std::min<size_t>(items.size(), 8192);
         hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, own.s, d_items.as<PackItem>(), (uint32_t)items.size(),
@@ -941,18 +941,39 @@ static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dc
         std::memcpy(out[i].minmax, mm.data() + e->minmax_off[i], 16ull * tiles[i].instants);
     }
     // encoded bytes: device slots -> pinned buffer (async, one copy per tile) -> the caller's buffers (threads)
-    if (!ring_lock.owns_lock()) ring_lock.lock();
+    if (ring_lock.owns_lock()) ring_lock.unlock();
+    return k2r::encoder_download(e, [&](size_t i, uint64_t) { return out[i].bytes; });
+}
+
+namespace k2r {
+void host_parallel_for(size_t n, const std::function<void(size_t)>& f) { parallel_for(n, f); }
+
+int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst) {
+    const size_t n = e->desc.size();
+    std::vector<uint64_t> lens(n, 0);
+    for (size_t i = 0; i < n; i++)
+        if (e->pre_status[i] == DCDF_OK && e->results[i].status == ST_OK) lens[i] = e->results[i].len;
+    PinRing& ring = pin_ring();
+    std::lock_guard<std::mutex> ring_lock(ring.mu);
     if (!ring.init()) return DCDF_ERR_NOMEM;
     size_t i = 0;
     int fill = 0;
     std::vector<size_t> pend[2];
     std::vector<uint64_t> pend_off[2];
+    bool failed = false;
     auto drain = [&](int b) -> bool {
         if (!ring.wait(b)) return false;
         const uint8_t* pb = (const uint8_t*)ring.buf[b];
-        parallel_for(pend[b].size(), [&](size_t q) { std::memcpy(out[pend[b][q]].bytes, pb + pend_off[b][q], lens[pend[b][q]]); });
+        std::atomic<bool> bad{false};
+        parallel_for(pend[b].size(), [&](size_t q) {
+            const size_t ti = pend[b][q];
+            uint8_t* d = dst(ti, lens[ti]);
+            if (!d) bad = true;
+            else std::memcpy(d, pb + pend_off[b][q], lens[ti]);
+        });
         pend[b].clear();
         pend_off[b].clear();
+        failed = failed || bad;
         return true;
     };
     while (i < n) {
@@ -961,7 +982,9 @@ static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dc
             continue;
         }
         if (lens[i] > kPinBytes) {  // oversize result: plain copy
-            K2R_HIP(hipMemcpy(out[i].bytes, e->args[i].out, lens[i], hipMemcpyDeviceToHost));
+            uint8_t* d = dst(i, lens[i]);
+            if (!d) return DCDF_ERR_NOMEM;
+            K2R_HIP(hipMemcpy(d, e->args[i].out, lens[i], hipMemcpyDeviceToHost));
             i++;
             continue;
         }
@@ -982,8 +1005,9 @@ static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dc
         fill++;
     }
     if (!drain(0) || !drain(1)) return DCDF_ERR_NO_DEVICE;
-    return DCDF_OK;
+    return failed ? DCDF_ERR_NOMEM : DCDF_OK;
 }
+}  // namespace k2r
 
 extern "C" int dcdf_chunk_build_batch(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dcdf_encoded** out) {
     if (!tiles || !out || n == 0 || (mem != DCDF_MEM_HOST && mem != DCDF_MEM_DEVICE)) return DCDF_ERR_BAD_ARG;

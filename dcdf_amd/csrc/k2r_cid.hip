@@ -65,16 +65,18 @@ __global__ void __launch_bounds__(64) k_object_sha256(const TileArgs* __restrict
     const uint64_t nblk = (total + 1 + 8 + 63) / 64;      // + 0x80 + 64-bit length
     const bool aligned = ((uintptr_t)data & 7) == 0;
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    // The 64 lanes of a wave read 64 different chunks, so a block's eight loads are eight latencies of scattered lines; they
+    // are issued one block ahead (nx) and land while the ~1 800 instructions of the current block run.
+    auto full_block = [&](uint64_t b) { return aligned && b > 0 && 64 * b + 64 <= total; };  // chunk bytes only, aligned words
+    uint2 nx[8];
     for (uint64_t b = 0; b < nblk; b++) {
         uint32_t w[16];
         const uint64_t o = 64 * b;
-        if (aligned && b > 0 && o + 64 <= total) {  // a full block of chunk bytes: aligned big-endian words
-            const uint2* p = (const uint2*)(data + (o - 8));  // 8-byte aligned: the header shifts the stream by 8
+        if (full_block(b)) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const uint2 v = p[j];
-                w[2 * j] = __builtin_bswap32(v.x);
-                w[2 * j + 1] = __builtin_bswap32(v.y);
+                w[2 * j] = __builtin_bswap32(nx[j].x);
+                w[2 * j + 1] = __builtin_bswap32(nx[j].y);
             }
         } else {
 #pragma unroll
@@ -88,6 +90,11 @@ __global__ void __launch_bounds__(64) k_object_sha256(const TileArgs* __restrict
                 w[14] = (uint32_t)(bits >> 32);
                 w[15] = (uint32_t)bits;
             }
+        }
+        if (b + 1 < nblk && full_block(b + 1)) {  // 8-byte aligned: the header shifts the stream by 8
+            const uint2* p = (const uint2*)(data + (o + 64 - 8));
+#pragma unroll
+            for (int j = 0; j < 8; j++) nx[j] = p[j];
         }
         sha256_block(h, w);
     }

@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/dcdf_k2r.h"
 #include "k2r_common.h"
@@ -33,18 +36,79 @@ struct Runtime {
     static Runtime& get();  // lazily initialised; ok == false when no usable device
 };
 
+// A few large device blocks kept between calls.  hipMalloc / hipFree of gigabytes cost tens of milliseconds each (and hipFree
+// synchronises the device); a caller that appends slice after slice (Variable::append -> dcdf_superchunk_build) asks for the
+// same sizes again and again.  Only the big, write-before-read buffers of a session go through it (output slots, packing and
+// scratch areas: DevBuf::alloc_pooled); contents are never assumed.  K2R_POOL=0 disables it.  The pool is never destroyed: HIP
+// calls at static-destruction time are not safe.
+struct DevPool {
+    struct Blk {
+        void* p;
+        size_t n;
+    };
+    std::mutex mu;
+    std::vector<Blk> blocks;  // oldest first
+    size_t held = 0;
+    static constexpr size_t kMinBytes = 16u << 20, kMaxHeld = 12ull << 30, kMaxBlocks = 12;
+    static DevPool& get() {
+        static DevPool* pool = new DevPool();
+        return *pool;
+    }
+    static bool enabled() {
+        static const bool on = [] {
+            const char* e = std::getenv("K2R_POOL");
+            return !(e && e[0] == '0');
+        }();
+        return on;
+    }
+    void* take(size_t n, size_t* got) {  // the smallest kept block of n .. 1.5 n bytes
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); i++)
+            if (blocks[i].n >= n && blocks[i].n <= n + n / 2 && (best == blocks.size() || blocks[i].n < blocks[best].n)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void* p = blocks[best].p;
+        *got = blocks[best].n;
+        held -= blocks[best].n;
+        blocks.erase(blocks.begin() + (long)best);
+        return p;
+    }
+    void give(void* p, size_t n) {
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (n < kMinBytes || n > kMaxHeld) drop.push_back(Blk{p, n});
+            else {
+                blocks.push_back(Blk{p, n});
+                held += n;
+                while (held > kMaxHeld || blocks.size() > kMaxBlocks) {
+                    drop.push_back(blocks.front());
+                    held -= blocks.front().n;
+                    blocks.erase(blocks.begin());
+                }
+            }
+        }
+        for (const Blk& b : drop) (void)hipFree(b.p);
+    }
+};
+
 // RAII device buffer
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool pooled = false;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (pooled) DevPool::get().give(p, bytes);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
+        pooled = false;
     }
     hipError_t alloc(size_t n) {
         release();
@@ -54,9 +118,60 @@ struct DevBuf {
         else p = nullptr;
         return e;
     }
+    // for large buffers that are written before they are read (see DevPool); `bytes` may come back larger than asked
+    hipError_t alloc_pooled(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        if (DevPool::enabled() && n >= DevPool::kMinBytes) {
+            size_t got = 0;
+            if (void* q = DevPool::get().take(n, &got)) {
+                p = q;
+                bytes = got;
+                pooled = true;
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) {
+            bytes = n;
+            pooled = DevPool::enabled() && n >= DevPool::kMinBytes;
+        } else {
+            p = nullptr;
+            if (DevPool::enabled()) {  // out of memory with blocks parked in the pool: give them back and try once more
+                DevPool& pool = DevPool::get();
+                std::vector<DevPool::Blk> all;
+                {
+                    std::lock_guard<std::mutex> lk(pool.mu);
+                    all.swap(pool.blocks);
+                    pool.held = 0;
+                }
+                for (const DevPool::Blk& b : all) (void)hipFree(b.p);
+                if (!all.empty()) {
+                    (void)hipGetLastError();
+                    e = hipMalloc(&p, n);
+                    if (e == hipSuccess) {
+                        bytes = n;
+                        pooled = n >= DevPool::kMinBytes;
+                    } else {
+                        p = nullptr;
+                    }
+                }
+            }
+        }
+        return e;
+    }
     template <class T>
     T* as() const { return (T*)p; }
 };
+
+}  // namespace k2r
+struct dcdf_encoder;
+namespace k2r {
+// The encoded bytes of a finished session, device slots -> pinned double buffer -> wherever `dst(tile, len)` says (called once
+// per tile with bytes, from worker threads; it may allocate the destination there).  k2r_capi_encode.hip.
+int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst);
+// runs f(0..n) on a few host threads
+void host_parallel_for(size_t n, const std::function<void(size_t)>& f);
 
 inline int map_status(int32_t st) {
     switch (st) {

@@ -17,6 +17,8 @@
 //   * SHA-256 of every stored object: `k_sha256_buffers` (k2r_cid.hip).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -383,12 +385,15 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
                 if (t.joinable()) t.join();
             }
         } join{sha};
-        uint64_t packed = 0, mmw = 0;
-        rc = dcdf_encoder_gather_size(g.e, &packed, &mmw);
-        if (rc != DCDF_OK) return rc;
-        std::vector<uint8_t> bytes(packed ? packed : 1);
-        std::vector<uint64_t> offs(nc), lens(nc);
-        rc = dcdf_encoder_gather(g.e, bytes.data(), bytes.size(), offs.data(), lens.data(), nullptr);
+        // the bytes come to the host through the pinned double buffer and land, framed, in their final objects: header + tag
+        // written, then the chunk bytes copied in by the download's worker threads (no intermediate host copy)
+        const std::string hd = header(2) + std::string(1, (char)4);  // NODE_MMSTRUCT3, NODE_SUBCHUNK (mmstruct.rs:215-218)
+        rc = k2r::encoder_download(g.e, [&](size_t q, uint64_t len) {
+            std::string& o = subs[chunk_sub[q]].obj;
+            o.assign(hd);
+            o.resize(hd.size() + len);
+            return (uint8_t*)&o[hd.size()];
+        });
         if (rc != DCDF_OK) return rc;
         tm.lap("gather");
         for (size_t q = 0; q < nc; q++) {
@@ -397,12 +402,7 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             int32_t st = 0;
             (void)dcdf_encoder_result(g.e, q, &st, &len, &ns, &nl, nullptr);
             Sub& s = subs[chunk_sub[q]];
-            const std::string hd = header(2);  // NODE_MMSTRUCT3
-            s.obj.resize(hd.size() + 1 + lens[q]);
-            std::memcpy(&s.obj[0], hd.data(), hd.size());
-            s.obj[hd.size()] = 4;  // NODE_SUBCHUNK (mmstruct.rs:215-218)
-            std::memcpy(&s.obj[hd.size() + 1], bytes.data() + offs[q], lens[q]);
-            s.size = lens[q] + 1;
+            s.size = len + 1;
             s.snapshots = ns;
             s.logs = nl;
         }
@@ -578,17 +578,22 @@ extern "C" int dcdf_superchunk_build(const dcdf_tile_desc* buffer, const uint32_
         std::free(s);
         return DCDF_ERR_NOMEM;
     }
-    for (size_t i = 0; i < s->n_objects; i++) {
+    std::atomic<bool> nomem{false};
+    k2r::host_parallel_for(s->n_objects, [&](size_t i) {  // (hundreds of megabytes: a few threads)
         const std::string& o = i + 1 < s->n_objects ? cx.objects[i] : top.node;
         const std::string& c = i + 1 < s->n_objects ? cx.cids[i] : tcid[0];
         s->objects[i].bytes = (uint8_t*)std::malloc(o.size() ? o.size() : 1);
         if (!s->objects[i].bytes) {
-            dcdf_free_superchunk(s);
-            return DCDF_ERR_NOMEM;
+            nomem = true;
+            return;
         }
         std::memcpy(s->objects[i].bytes, o.data(), o.size());
         s->objects[i].len = o.size();
         std::memcpy(s->objects[i].cid, c.data(), 36);
+    });
+    if (nomem) {
+        dcdf_free_superchunk(s);
+        return DCDF_ERR_NOMEM;
     }
     s->size = top.size;
     s->elided = top.elided;
