@@ -1825,12 +1825,16 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             ex.stamp(10);
             // one work item per I record: the four height-1 children of an internal height-2 node.  Records are in
             // arrival order; their place in level order comes from the owner's prefixes.
-            ex.par_nosync([&](int tid, EncRegs&) {
+            // (two instantiations of each stash pass: when no record overflowed the pool -- 97 % of the instants, known from the
+            // counts -- the loop body has no LDS-or-global branch)
+            auto passI = [&](auto ovf_tag) {
+              constexpr bool OVF = decltype(ovf_tag)::value != 0;
+              ex.par_nosync([&](int tid, EncRegs&) {
                 const uint32_t offV1 = TT.offV[1], offZ1 = TT.offZ[1], offI1 = TT.offI[1], lt = TT.LT, ne = TT.LT - TT.M0;
                 const uint32_t lv1 = sh.pl.lngV[1], lm1 = sh.pl.lngM[1];
                 for (uint32_t k = (uint32_t)tid; k < nI2; k += NT) {
                     uint32_t rec[5];
-                    if (k < (uint32_t)SH::CAPI_REC) {
+                    if (!OVF || k < (uint32_t)SH::CAPI_REC) {
 #pragma unroll
                         for (int i = 0; i < 5; i++) rec[i] = sh.pool[5u * k + i];
                     } else {
@@ -1863,14 +1867,20 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                 }
                 guard_flush(ex);
-            });
+              });
+            };
+            const bool rec_ovf = stI > (uint32_t)SH::CAPI_REC || stQ > (uint32_t)SH::CAPQ_REC;
+            if (rec_ovf) passI(EmTag<1>{});
+            else passI(EmTag<0>{});
             ex.stamp(11);
             // one work item per Q record: the four cells of an internal quad
-            ex.par([&](int tid, EncRegs&) {
+            auto passQ = [&](auto ovf_tag) {
+              constexpr bool OVF = decltype(ovf_tag)::value != 0;
+              ex.par([&](int tid, EncRegs&) {
                 const uint32_t offV0 = TT.offV[0], lv0 = sh.pl.lngV[0];
                 for (uint32_t m = (uint32_t)tid; m < nI1; m += NT) {
                     uint32_t q[3];
-                    if (m < (uint32_t)SH::CAPQ_REC) {
+                    if (!OVF || m < (uint32_t)SH::CAPQ_REC) {
 #pragma unroll
                         for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::POOLW - 3u * (m + 1u) + i];
                     } else {
@@ -1884,7 +1894,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                                      lv0 + sh.pfx[1][own] + ((hdr >> 14) & 63u));
                 }
                 guard_flush(ex);
-            });
+              });
+            };
+            if (rec_ovf) passQ(EmTag<1>{});
+            else passQ(EmTag<0>{});
             ex.stamp(6);
             // T, eqB and the continuation bitmaps of both Dacs (serialized; rank prefixes kept for the top nodes)
             {
