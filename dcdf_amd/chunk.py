@@ -132,7 +132,7 @@ class Chunk:
             c._bytes = None
             c._fetch = (lambda j=j: fetch(j)) if fetch else None
             c._handle = C.c_void_p(hs[j])
-            c._read_info()
+            c._shape = None  # (dcdf_chunk_info on first use: thousands of handles are opened at once)
             out.append(c)
         return out
 
@@ -158,19 +158,25 @@ class Chunk:
             self._open()
         return self._handle
 
+    def _info(self):
+        if self._handle is None:
+            self._open()
+        elif self._shape is None:
+            self._read_info()
+
     @property
     def encoding(self):
-        self._h
+        self._info()
         return self._encoding
 
     @property
     def fractional_bits(self):
-        self._h
+        self._info()
         return self._fractional_bits
 
     @property
     def n_blocks(self):
-        self._h
+        self._info()
         return self._n_blocks
 
     # -- construction --------------------------------------------------------------------------
@@ -200,7 +206,7 @@ class Chunk:
         return len(self.write_to())
 
     def shape(self):  # chunk.rs:119
-        self._h
+        self._info()
         return list(self._shape)
 
     def close(self):

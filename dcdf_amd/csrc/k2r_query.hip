@@ -2,6 +2,9 @@
 // single-chunk and batched.  Kernels walk the serialized big-endian bytes in HBM via k2r_decode.h.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <mutex>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +19,11 @@
 using namespace k2r;
 
 struct dcdf_chunk {
-    std::vector<InstDesc> descs;  // one per instant, stream order == instant order
+    // one per instant, stream order == instant order.  A chunk opened from device memory (dcdf_chunk_open_batch) has them on
+    // the device only; the few host-side readers fetch them on first use (host_descs)
+    mutable std::vector<InstDesc> descs;
+    mutable std::once_flag descs_once;
+    uint32_t k0 = 0, sidelen0 = 0;  // of instant 0 (== every instant's)
     uint32_t instants = 0, rows = 0, cols = 0, n_blocks = 0;
     int32_t encoding = 0;
     uint32_t fbits = 0;
@@ -43,6 +50,20 @@ struct dcdf_chunk {
     // cells in range, so such instants are searched by the per-thread replica of that descent, not by the decoding wave walk.
     std::vector<uint8_t> search_quirk;
 };
+
+// the host copy of a chunk's instant descriptors
+static const std::vector<InstDesc>& host_descs(const dcdf_chunk* h) {
+    std::call_once(h->descs_once, [h] {
+        if (h->descs.empty() && h->p_descs && h->instants) {
+            h->descs.resize(h->instants);
+            if (hipMemcpy(h->descs.data(), h->p_descs, (size_t)h->instants * sizeof(InstDesc), hipMemcpyDeviceToHost) != hipSuccess) {
+                (void)hipGetLastError();
+                h->descs.clear();
+            }
+        }
+    });
+    return h->descs;
+}
 
 namespace k2r {
 
@@ -1207,6 +1228,8 @@ extern "C" int dcdf_chunk_open(const uint8_t* bytes, size_t len, dcdf_chunk** h)
         }
     }
     c->instants = (uint32_t)c->descs.size();
+    c->k0 = c->descs[0].k;
+    c->sidelen0 = c->descs[0].sidelen;
     c->rows = c->descs[0].rows;  // chunk.rs:119-123
     c->cols = c->descs[0].cols;
     for (const InstDesc& d : c->descs)
@@ -1283,6 +1306,17 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
         }
         return status ? DCDF_OK : first_err;
     }
+    struct OpenTimer {  // K2R_OPEN_TIMING=1: wall time of the steps on stderr (diagnostics; the laps synchronise the device)
+        const bool on = std::getenv("K2R_OPEN_TIMING") != nullptr;
+        std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        void lap(const char* what) {
+            if (!on) return;
+            (void)hipDeviceSynchronize();
+            const auto u = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "k2r-open %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(u - t).count());
+            t = u;
+        }
+    } tm;
     auto slab = std::make_shared<BatchSlab>();
     std::vector<SlabItem> items(n);
     std::vector<uint64_t> offs(n);
@@ -1300,6 +1334,7 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
     hipLaunchKernelGGL(k_slab_pack, dim3((uint32_t)std::min<size_t>(n, 8192)), dim3(256), 0, 0, d_items.as<SlabItem>(), (uint32_t)n,
                        slab->bytes.as<uint8_t>());
     K2R_HIP(hipGetLastError());
+    tm.lap("slab alloc + pack");
     K2R_HIP(d_offs.alloc(n * 8));
     K2R_HIP(d_lens.alloc(n * 8));
     K2R_HIP(hipMemcpy(d_offs.p, offs.data(), n * 8, hipMemcpyHostToDevice));
@@ -1312,6 +1347,7 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
     K2R_HIP(hipGetLastError());
     std::vector<OpenMeta> meta(n);
     K2R_HIP(hipMemcpy(meta.data(), d_meta.p, n * sizeof(OpenMeta), hipMemcpyDeviceToHost));
+    tm.lap("parse pass 1");
     std::vector<uint32_t> first(n + 1, 0);
     for (size_t i = 0; i < n; i++) first[i + 1] = first[i] + (meta[i].ok ? meta[i].n_inst : 0u);
     const uint32_t total_inst = first[n];
@@ -1335,8 +1371,7 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
     K2R_HIP(hipMemcpy(meta2.data(), d_meta.p, n * sizeof(OpenMeta), hipMemcpyDeviceToHost));
     std::vector<uint8_t> quirk(total_inst);
     K2R_HIP(hipMemcpy(quirk.data(), d_quirk.p, total_inst, hipMemcpyDeviceToHost));
-    std::vector<InstDesc> descs(total_inst);
-    K2R_HIP(hipMemcpy(descs.data(), slab->descs.p, (size_t)total_inst * sizeof(InstDesc), hipMemcpyDeviceToHost));
+    tm.lap("parse pass 2 + descs D2H");
     // side-16 tables for the k = 2 chunks of sidelen 32..256: one slab, one launch
     const bool want_top = !std::getenv("K2R_NO_TOP_TABLE");
     std::vector<uint64_t> top_off(n, 0);
@@ -1382,6 +1417,7 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
         K2R_HIP(hipGetLastError());
         K2R_HIP(hipMemcpy(ovf.data(), d_ovf.p, n * 4, hipMemcpyDeviceToHost));
     }
+    tm.lap("top tables");
     K2R_HIP(hipDeviceSynchronize());
     int first_err = DCDF_OK;
     for (size_t i = 0; i < n; i++) {
@@ -1399,8 +1435,9 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
             }
             return DCDF_ERR_NOMEM;
         }
-        c->descs.assign(descs.begin() + first[i], descs.begin() + first[i + 1]);
         c->instants = meta[i].n_inst;
+        c->k0 = meta[i].k;
+        c->sidelen0 = meta[i].sidelen;
         c->rows = meta[i].rows;
         c->cols = meta[i].cols;
         c->n_blocks = meta[i].n_blocks;
@@ -1417,6 +1454,7 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
         c->store = slab;
         out[i] = c.release();
     }
+    tm.lap("handles");
     return status ? DCDF_OK : first_err;
 }
 extern "C" int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* encoding, uint32_t* fractional_bits,
@@ -1438,9 +1476,11 @@ extern "C" int dcdf_chunk_info(const dcdf_chunk* h, uint32_t shape[3], int32_t* 
 // "encoded bytes of the touched chunks' touched structures").  Host metadata only.
 extern "C" int dcdf_chunk_instant_layout(const dcdf_chunk* h, uint64_t* off, uint32_t* snapshot_of) {
     if (!h || !off) return DCDF_ERR_BAD_ARG;
+    const std::vector<InstDesc>& descs = host_descs(h);
+    if (descs.size() != h->instants) return DCDF_ERR_INTERNAL;
     for (uint32_t i = 0; i < h->instants; i++) {
-        off[i] = (uint64_t)h->descs[i].T.idx_off - 8 - 13;  // BitMap header (len, k) and the 13-byte instant header before it
-        if (snapshot_of) snapshot_of[i] = h->descs[i].snap;
+        off[i] = (uint64_t)descs[i].T.idx_off - 8 - 13;  // BitMap header (len, k) and the 13-byte instant header before it
+        if (snapshot_of) snapshot_of[i] = descs[i].snap;
     }
     off[h->instants] = h->len;
     return DCDF_OK;
@@ -1655,10 +1695,10 @@ static void window_items(uint32_t chunk, const dcdf_cube& c, uint64_t out_base, 
 }
 // the wave kernel handles k * k <= 64 children per node and 16-bit coordinates
 static bool wave_kernel_ok(const dcdf_chunk* h) {
-    const uint32_t k = h->descs[0].k;
-    return k * k <= 64 && h->descs[0].sidelen <= 65535;
+    const uint32_t k = h->k0;
+    return k * k <= 64 && h->sidelen0 <= 65535;
 }
-static bool node_kernel_ok(const dcdf_chunk* h) { return h->descs[0].k == 2 && h->descs[0].sidelen >= 4; }
+static bool node_kernel_ok(const dcdf_chunk* h) { return h->k0 == 2 && h->sidelen0 >= 4; }
 static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>& items, void* d_out, int32_t dtype, hipEvent_t e0, hipEvent_t e1,
                                bool node_wise, bool narrow) {
     DevBuf d_items;
