@@ -1328,7 +1328,7 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
         tot += (lens[i] + 64 + 15) & ~15ull;  // (slack: the wave decoder reads whole 16-byte blocks at a stream's tail)
     }
     DevBuf d_items, d_offs, d_lens, d_first, d_meta, d_quirk, d_ic, d_ovf;
-    K2R_HIP(slab->bytes.alloc(tot));
+    K2R_HIP(slab->bytes.alloc_pooled(tot));  // (gigabytes: hipMalloc takes 4 .. 60 ms for them, depending on what the driver has to clear)
     K2R_HIP(d_items.alloc(n * sizeof(SlabItem)));
     K2R_HIP(hipMemcpy(d_items.p, items.data(), n * sizeof(SlabItem), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_slab_pack, dim3((uint32_t)std::min<size_t>(n, 8192)), dim3(256), 0, 0, d_items.as<SlabItem>(), (uint32_t)n,
@@ -1699,25 +1699,28 @@ static bool wave_kernel_ok(const dcdf_chunk* h) {
     return k * k <= 64 && h->sidelen0 <= 65535;
 }
 static bool node_kernel_ok(const dcdf_chunk* h) { return h->k0 == 2 && h->sidelen0 >= 4; }
+static int launch_window_items_dev(const DevBuf& d_refs, const WinItem* d_items, uint32_t n, void* d_out, int32_t dtype, hipEvent_t e0, hipEvent_t e1,
+                                   bool node_wise, bool narrow) {
+    const uint32_t grid = std::min<uint32_t>((n + 3) / 4, 256u * 16u);
+    if (e0) K2R_HIP(hipEventRecord(e0, 0));
+    if (node_wise) {
+        if (dtype == DCDF_I64 && narrow) hipLaunchKernelGGL((k_window_wave2<4, true, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items, n, d_out, dtype);
+        else if (dtype == DCDF_I64) hipLaunchKernelGGL((k_window_wave2<3, true>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items, n, d_out, dtype);
+        else if (narrow) hipLaunchKernelGGL((k_window_wave2<4, false, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items, n, d_out, dtype);
+        else hipLaunchKernelGGL((k_window_wave2<3, false>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items, n, d_out, dtype);
+    }
+    else hipLaunchKernelGGL(k_window_wave, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items, n, d_out, dtype);
+    if (e1) K2R_HIP(hipEventRecord(e1, 0));
+    K2R_HIP(hipGetLastError());
+    K2R_HIP(hipDeviceSynchronize());
+    return DCDF_OK;
+}
 static int launch_window_items(const DevBuf& d_refs, const std::vector<WinItem>& items, void* d_out, int32_t dtype, hipEvent_t e0, hipEvent_t e1,
                                bool node_wise, bool narrow) {
     DevBuf d_items;
     K2R_HIP(d_items.alloc(items.size() * sizeof(WinItem)));
     K2R_HIP(hipMemcpy(d_items.p, items.data(), items.size() * sizeof(WinItem), hipMemcpyHostToDevice));
-    const uint32_t n = (uint32_t)items.size();
-    const uint32_t grid = std::min<uint32_t>((n + 3) / 4, 256u * 16u);
-    if (e0) K2R_HIP(hipEventRecord(e0, 0));
-    if (node_wise) {
-        if (dtype == DCDF_I64 && narrow) hipLaunchKernelGGL((k_window_wave2<4, true, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
-        else if (dtype == DCDF_I64) hipLaunchKernelGGL((k_window_wave2<3, true>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
-        else if (narrow) hipLaunchKernelGGL((k_window_wave2<4, false, false, int32_t>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
-        else hipLaunchKernelGGL((k_window_wave2<3, false>), dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
-    }
-    else hipLaunchKernelGGL(k_window_wave, dim3(grid), dim3(256), 0, 0, d_refs.as<ChunkRef>(), d_items.as<WinItem>(), n, d_out, dtype);
-    if (e1) K2R_HIP(hipEventRecord(e1, 0));
-    K2R_HIP(hipGetLastError());
-    K2R_HIP(hipDeviceSynchronize());
-    return DCDF_OK;
+    return launch_window_items_dev(d_refs, d_items.as<WinItem>(), (uint32_t)items.size(), d_out, dtype, e0, e1, node_wise, narrow);
 }
 
 // ---- windows ----------------------------------------------------------------------------------------------
@@ -2134,37 +2137,106 @@ static void raster_pieces(const dcdf_raster* r, const dcdf_cube& c, F&& f) {
                 f((uint32_t)(((uint64_t)seg * r->nti + ti) * r->ntj + tj), l, t0, r0, c0);
             }
 }
+// One thread per dataset-level cube: the wave items of its pieces (the loops of raster_pieces x window_items), written at
+// item_base[q]; the host only counts them (a closed form per cube) -- 24 bytes per item need not cross PCIe.
+struct RasterGeom {
+    uint32_t T, R, C, tile, cs, nti, ntj, step;  // step: 64 (node-wise walk) or 32
+};
+__global__ void __launch_bounds__(256)
+k_raster_expand(const dcdf_cube* __restrict__ cubes, const uint64_t* __restrict__ out_base, const uint32_t* __restrict__ item_base, uint32_t nq,
+                RasterGeom g, WinItem* __restrict__ items) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    dcdf_cube c = cubes[q];
+    if (c.start > c.end) { const uint32_t x = c.start; c.start = c.end; c.end = x; }  // helpers.rs:7-16 (norm_cube)
+    if (c.top > c.bottom) { const uint32_t x = c.top; c.top = c.bottom; c.bottom = x; }
+    if (c.left > c.right) { const uint32_t x = c.left; c.left = c.right; c.right = x; }
+    const uint64_t wr = c.bottom - c.top, wc = c.right - c.left;
+    if ((uint64_t)(c.end - c.start) * wr * wc == 0) return;
+    WinItem* o = items + item_base[q];
+    const uint64_t base = out_base[q];
+    for (uint32_t seg = c.start / g.cs; seg <= (c.end - 1) / g.cs; seg++)
+        for (uint32_t ti = c.top / g.tile; ti <= (c.bottom - 1) / g.tile; ti++)
+            for (uint32_t tj = c.left / g.tile; tj <= (c.right - 1) / g.tile; tj++) {
+                const uint32_t t0 = seg * g.cs, r0 = ti * g.tile, c0 = tj * g.tile;
+                const uint32_t ls = max(c.start, t0) - t0, le = min(c.end, t0 + g.cs) - t0, lt = max(c.top, r0) - r0, lb = min(c.bottom, r0 + g.tile) - r0,
+                               ll = max(c.left, c0) - c0, lr = min(c.right, c0 + g.tile) - c0;
+                const uint32_t cid = (seg * g.nti + ti) * g.ntj + tj;
+                const uint64_t at = base + ((uint64_t)(t0 + ls - c.start) * wr + (r0 + lt - c.top)) * wc + (c0 + ll - c.left);
+                const uint32_t rs = g.step == 64 ? lt : (lt & ~31u), cs0 = g.step == 64 ? ll : (ll & ~31u);
+                for (uint32_t t = ls; t < le; t++)
+                    for (uint32_t rr = rs; rr < lb; rr += g.step)
+                        for (uint32_t cc = cs0; cc < lr; cc += g.step) {
+                            WinItem it;
+                            it.chunk = cid;
+                            it.inst = t;
+                            it.top = (uint16_t)max(rr, lt);
+                            it.bottom = (uint16_t)min(rr + g.step, lb);
+                            it.left = (uint16_t)max(cc, ll);
+                            it.right = (uint16_t)min(cc + g.step, lr);
+                            it.out_sr = (uint32_t)wc;
+                            it.out_off = at + (uint64_t)(t - ls) * wr * wc + (uint64_t)(it.top - lt) * wc + (it.left - ll);
+                            *o++ = it;
+                        }
+            }
+}
+// wave items of one cube (the count of the loops above)
+static uint64_t raster_item_count(const dcdf_raster* r, const dcdf_cube& c, uint32_t step) {
+    auto along = [&](uint32_t a, uint32_t b, uint32_t unit) {  // sum over the tiles [a, b) meets of ceil(piece / step) (from the piece's start, or the 32-grid)
+        uint64_t n = 0;
+        for (uint32_t t = a / unit; t <= (b - 1) / unit; t++) {
+            const uint32_t lo = std::max(a, t * unit) - t * unit, hi = std::min(b, t * unit + unit) - t * unit;
+            const uint32_t from = step == 64 ? lo : (lo & ~31u);
+            n += (hi - from + step - 1) / step;
+        }
+        return n;
+    };
+    return (uint64_t)(c.end - c.start) * along(c.top, c.bottom, r->tile) * along(c.left, c.right, r->tile);
+}
+
 extern "C" int dcdf_raster_fill_window_batch(const dcdf_raster* r, const dcdf_cube* cubes, size_t nq, void* out, int32_t out_dtype,
                                              int out_mem, const uint64_t* out_offset, float* kernel_ms) {
-    if (!r || !cubes || !out || !out_offset || nq == 0) return DCDF_ERR_BAD_ARG;
+    if (!r || !cubes || !out || !out_offset || nq == 0 || nq > 0x7fffffffu) return DCDF_ERR_BAD_ARG;
     if (out_dtype != DCDF_I32 && out_dtype != DCDF_I64 && out_dtype != DCDF_F32 && out_dtype != DCDF_F64) return DCDF_ERR_BAD_ARG;
     if (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE) return DCDF_ERR_BAD_ARG;
     if (!r->all_wave) return DCDF_ERR_UNSUPPORTED;  // arities beyond the wave walk (k * k > 64): use the per-chunk entry points
     const size_t es = (out_dtype == DCDF_I32 || out_dtype == DCDF_F32) ? 4 : 8;
     const bool to_dev = out_mem == DCDF_MEM_DEVICE;
-    std::vector<WinItem> items;
-    uint64_t total = 0;
+    const uint32_t step = r->all_node ? 64u : 32u;
+    // host: bounds, where each window goes, how many wave items it makes; device: the items themselves (k_raster_expand)
+    std::vector<uint64_t> base(nq);
+    std::vector<uint32_t> item_base(nq);
+    uint64_t total = 0, n_items = 0;
     bool dense = true;
     for (size_t q = 0; q < nq; q++) {
         const dcdf_cube c = norm_cube(cubes[q]);
         if (c.end > r->T || c.bottom > r->R || c.right > r->C) return DCDF_ERR_BOUNDS;
-        const uint64_t wt = c.end - c.start, wr = c.bottom - c.top, wc = c.right - c.left;
+        const uint64_t cells = (uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left);
         dense = dense && out_offset[q] == total + out_offset[0];
-        const uint64_t base = to_dev ? out_offset[q] : total;
-        total += wt * wr * wc;
-        if (wt * wr * wc == 0) continue;
-        raster_pieces(r, c, [&](uint32_t cid, const dcdf_cube& l, uint32_t t0, uint32_t r0, uint32_t c0) {
-            const uint64_t at = base + ((uint64_t)(t0 + l.start - c.start) * wr + (r0 + l.top - c.top)) * wc + (c0 + l.left - c.left);
-            window_items(cid, l, at, items, r->all_node, wc, wr * wc);
-        });
+        base[q] = to_dev ? out_offset[q] : total;
+        total += cells;
+        item_base[q] = (uint32_t)n_items;
+        if (cells) n_items += raster_item_count(r, c, step);
+        if (n_items > 0xfffffff0ull) return DCDF_ERR_CAPACITY;
     }
-    if (items.empty()) return DCDF_OK;
-    if (items.size() > 0xfffffff0ull) return DCDF_ERR_CAPACITY;
-    DevBuf d_o;
-    if (!to_dev) K2R_HIP(d_o.alloc(total * es));
+    if (n_items == 0) return DCDF_OK;
+    DevBuf d_o, d_cubes, d_base, d_ibase, d_items;
+    if (!to_dev) K2R_HIP(d_o.alloc_pooled(total * es));
+    K2R_HIP(d_cubes.alloc(nq * sizeof(dcdf_cube)));
+    K2R_HIP(d_base.alloc(nq * 8));
+    K2R_HIP(d_ibase.alloc(nq * 4));
+    K2R_HIP(d_items.alloc_pooled(n_items * sizeof(WinItem)));
+    K2R_HIP(hipMemcpy(d_cubes.p, cubes, nq * sizeof(dcdf_cube), hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_base.p, base.data(), nq * 8, hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_ibase.p, item_base.data(), nq * 4, hipMemcpyHostToDevice));
+    const RasterGeom g{r->T, r->R, r->C, r->tile, r->cs, r->nti, r->ntj, step};
+    hipLaunchKernelGGL(k_raster_expand, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, 0, d_cubes.as<dcdf_cube>(), d_base.as<uint64_t>(),
+                       d_ibase.as<uint32_t>(), (uint32_t)nq, g, d_items.as<WinItem>());
+    K2R_HIP(hipGetLastError());
     EventPair ev;
     K2R_HIP(ev.create());
-    const int rc = launch_window_items(r->d_refs, items, to_dev ? out : d_o.p, out_dtype, ev.e0, ev.e1, r->all_node, r->all_narrow);
+    const int rc = launch_window_items_dev(r->d_refs, d_items.as<WinItem>(), (uint32_t)n_items, to_dev ? out : d_o.p, out_dtype, ev.e0, ev.e1,
+                                           r->all_node, r->all_narrow);
     if (rc != DCDF_OK) return rc;
     if (!to_dev) {
         if (dense) {
