@@ -2090,6 +2090,7 @@ struct dcdf_raster {
     std::vector<dcdf_chunk*> chunks;  // [(segment * nti + ti) * ntj + tj]
     uint32_t T = 0, R = 0, C = 0, tile = 0, cs = 0, nseg = 0, nti = 0, ntj = 0;
     DevBuf d_refs;
+    DevBuf d_quirk;  // [chunk][chunk_size]: dcdf_chunk::search_quirk of every instant (k_raster_search_expand)
     bool all_wave = true, all_node = true, all_narrow = true;
 };
 extern "C" int dcdf_raster_create(dcdf_chunk* const* chunks, size_t n_chunks, const uint32_t shape[3], uint32_t tile, uint32_t chunk_size,
@@ -2120,6 +2121,11 @@ extern "C" int dcdf_raster_create(dcdf_chunk* const* chunks, size_t n_chunks, co
     }
     K2R_HIP(r->d_refs.alloc(n_chunks * sizeof(ChunkRef)));
     K2R_HIP(hipMemcpy(r->d_refs.p, refs.data(), n_chunks * sizeof(ChunkRef), hipMemcpyHostToDevice));
+    std::vector<uint8_t> quirk(n_chunks * (size_t)chunk_size, 0);
+    for (size_t i = 0; i < n_chunks; i++)
+        for (size_t t = 0; t < chunks[i]->search_quirk.size() && t < chunk_size; t++) quirk[i * chunk_size + t] = chunks[i]->search_quirk[t];
+    K2R_HIP(r->d_quirk.alloc(quirk.size()));
+    K2R_HIP(hipMemcpy(r->d_quirk.p, quirk.data(), quirk.size(), hipMemcpyHostToDevice));
     *out = r.release();
     return DCDF_OK;
 }
@@ -2258,10 +2264,235 @@ extern "C" int dcdf_raster_fill_window_batch(const dcdf_raster* r, const dcdf_cu
     if (kernel_ms) *kernel_ms = ms;
     return DCDF_OK;
 }
+// ---- search of dataset-level cubes with everything but a count per cube on the device ---------------------------------
+// One thread per cube writes what search_impl builds on the host: a WinQuery per chunk-level piece (with the chunk's origin
+// for the emit kernel), a SearchItem per (piece, instant), a WinItem + SearchExtra per <= 64 x 64 part of it.
+__global__ void __launch_bounds__(256)
+k_raster_search_expand(const dcdf_cube* __restrict__ cubes, const int64_t* __restrict__ lower, const int64_t* __restrict__ upper,
+                       const uint32_t* __restrict__ sb, const uint32_t* __restrict__ ib, const uint32_t* __restrict__ wb, uint32_t nq, RasterGeom g,
+                       const uint8_t* __restrict__ quirk, WinQuery* __restrict__ qs, SearchItem* __restrict__ items, WinItem* __restrict__ witems,
+                       SearchExtra* __restrict__ sx) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    dcdf_cube c = cubes[q];
+    if (c.start > c.end) { const uint32_t x = c.start; c.start = c.end; c.end = x; }
+    if (c.top > c.bottom) { const uint32_t x = c.top; c.top = c.bottom; c.bottom = x; }
+    if (c.left > c.right) { const uint32_t x = c.left; c.left = c.right; c.right = x; }
+    if ((uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left) == 0) return;
+    const int64_t lo = min(lower[q], upper[q]), hi = max(lower[q], upper[q]);  // helpers.rs:7-16 via chunk.rs:214
+    uint32_t s = sb[q], it = ib[q], w = wb[q];
+    for (uint32_t seg = c.start / g.cs; seg <= (c.end - 1) / g.cs; seg++)
+        for (uint32_t ti = c.top / g.tile; ti <= (c.bottom - 1) / g.tile; ti++)
+            for (uint32_t tj = c.left / g.tile; tj <= (c.right - 1) / g.tile; tj++) {
+                const uint32_t t0 = seg * g.cs, r0 = ti * g.tile, c0 = tj * g.tile;
+                const uint32_t ls = max(c.start, t0) - t0, le = min(c.end, t0 + g.cs) - t0, lt = max(c.top, r0) - r0, lb = min(c.bottom, r0 + g.tile) - r0,
+                               ll = max(c.left, c0) - c0, lr = min(c.right, c0 + g.tile) - c0;
+                const uint32_t cid = (seg * g.nti + ti) * g.ntj + tj;
+                WinQuery Q;
+                Q.chunk = cid;
+                Q.start = ls; Q.end = le; Q.top = lt; Q.bottom = lb; Q.left = ll; Q.right = lr;
+                Q._pad = t0;  // the chunk's origin inside the raster, added to every triple by k_search_emit
+                Q.lower = lo;
+                Q.upper = hi;
+                Q.out_off = (uint64_t)r0 | (uint64_t)c0 << 32;
+                qs[s] = Q;
+                const uint32_t ncb = (lr - ll + 63u) >> 6;
+                for (uint32_t t = ls; t < le; t++) {
+                    items[it++] = SearchItem{s, t, 0, w, ncb};
+                    const uint32_t qk = quirk[(size_t)cid * g.cs + t];
+                    for (uint32_t rr = lt; rr < lb; rr += 64)
+                        for (uint32_t cc = ll; cc < lr; cc += 64) {
+                            WinItem wi;
+                            wi.chunk = cid;
+                            wi.inst = t;
+                            wi.top = (uint16_t)rr;
+                            wi.bottom = (uint16_t)min(rr + 64, lb);
+                            wi.left = (uint16_t)cc;
+                            wi.right = (uint16_t)min(cc + 64, lr);
+                            wi.out_sr = 0;
+                            wi.out_off = 0;
+                            witems[w] = wi;
+                            sx[w] = SearchExtra{lo, hi, qk, 0u};
+                            w++;
+                        }
+                }
+                s++;
+            }
+}
+// exclusive prefix sum of n uint32 counts into uint64 offsets: block sums, their scan by one block, the offsets
+constexpr uint32_t kScanPer = 2048;  // elements per 256-thread block
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ v, uint32_t n, uint64_t* __restrict__ sums) {
+    __shared__ uint64_t part[256];
+    const uint32_t b0 = blockIdx.x * kScanPer;
+    uint64_t a = 0;
+    for (uint32_t i = threadIdx.x; i < kScanPer && b0 + i < n; i += 256) a += v[b0 + i];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (uint32_t st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(256) k_scan_top(uint64_t* __restrict__ sums, uint32_t nb, uint64_t* __restrict__ total) {
+    // (one block; nb is small: n / 2048) sums[b] <- sum of the blocks before b
+    __shared__ uint64_t part[256];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint64_t x = i < nb ? sums[i] : 0;
+        part[threadIdx.x] = x;
+        __syncthreads();
+        for (uint32_t st = 1; st < 256; st <<= 1) {  // inclusive scan (Hillis-Steele)
+            const uint64_t y = threadIdx.x >= st ? part[threadIdx.x - st] : 0;
+            __syncthreads();
+            part[threadIdx.x] += y;
+            __syncthreads();
+        }
+        if (i < nb) sums[i] = carry + part[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t* __restrict__ v, uint32_t n, const uint64_t* __restrict__ sums,
+                                                    uint64_t* __restrict__ offs) {
+    // thread t of the block owns 8 consecutive elements: its prefix inside the block by a scan of the threads' sums
+    __shared__ uint64_t part[256];
+    const uint32_t b0 = blockIdx.x * kScanPer + threadIdx.x * 8;
+    uint32_t x[8];
+    uint64_t a = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        x[j] = b0 + j < n ? v[b0 + j] : 0u;
+        a += x[j];
+    }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (uint32_t st = 1; st < 256; st <<= 1) {
+        const uint64_t y = threadIdx.x >= st ? part[threadIdx.x - st] : 0;
+        __syncthreads();
+        part[threadIdx.x] += y;
+        __syncthreads();
+    }
+    uint64_t run = sums[blockIdx.x] + part[threadIdx.x] - a;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (b0 + j < n) offs[b0 + j] = run;
+        run += x[j];
+    }
+}
+// per cube: where its triples begin and how many there are (its items are consecutive)
+__global__ void __launch_bounds__(256) k_raster_query_counts(const uint32_t* __restrict__ ib, uint32_t nq, uint32_t ni, const uint64_t* __restrict__ offs,
+                                                             const uint64_t* __restrict__ total, uint64_t* __restrict__ counts,
+                                                             uint64_t* __restrict__ offsets) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t a = ib[q], b = ib[q + 1];
+    const uint64_t oa = a < ni ? offs[a] : *total, ob = b < ni ? offs[b] : *total;
+    offsets[q] = oa;
+    counts[q] = ob - oa;
+}
+
+static int raster_search_device(const dcdf_raster* r, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper, size_t nq, uint32_t* out,
+                                size_t cap, int out_mem, uint64_t* counts, uint64_t* offsets, float* kernel_ms) {
+    std::vector<uint32_t> sb(nq + 1), ib(nq + 1), wb(nq + 1);
+    uint64_t ns = 0, ni = 0, nw = 0;
+    for (size_t q = 0; q < nq; q++) {
+        const dcdf_cube c = norm_cube(cubes[q]);
+        if (c.end > r->T || c.bottom > r->R || c.right > r->C) return DCDF_ERR_BOUNDS;
+        sb[q] = (uint32_t)ns; ib[q] = (uint32_t)ni; wb[q] = (uint32_t)nw;
+        if ((uint64_t)(c.end - c.start) * (c.bottom - c.top) * (c.right - c.left) == 0) continue;
+        const uint64_t tiles = (uint64_t)((c.bottom - 1) / r->tile - c.top / r->tile + 1) * ((c.right - 1) / r->tile - c.left / r->tile + 1);
+        ns += ((c.end - 1) / r->cs - c.start / r->cs + 1) * tiles;
+        ni += (uint64_t)(c.end - c.start) * tiles;
+        nw += raster_item_count(r, c, 64);
+        if (nw + 4096 > 0xffffff00ull) return DCDF_ERR_CAPACITY;
+    }
+    sb[nq] = (uint32_t)ns; ib[nq] = (uint32_t)ni; wb[nq] = (uint32_t)nw;
+    for (size_t q = 0; q < nq; q++) counts[q] = offsets[q] = 0;
+    if (ni == 0) {
+        if (kernel_ms) *kernel_ms = 0.f;
+        return DCDF_OK;
+    }
+    DevBuf d_cubes, d_lo, d_hi, d_sb, d_ib, d_wb, d_qs, d_items, d_witems, d_sx, d_wbits, d_counts, d_sums, d_total, d_offs, d_qc, d_qo, d_out;
+    K2R_HIP(d_cubes.alloc(nq * sizeof(dcdf_cube)));
+    K2R_HIP(d_lo.alloc(nq * 8));
+    K2R_HIP(d_hi.alloc(nq * 8));
+    K2R_HIP(d_sb.alloc((nq + 1) * 4));
+    K2R_HIP(d_ib.alloc((nq + 1) * 4));
+    K2R_HIP(d_wb.alloc((nq + 1) * 4));
+    K2R_HIP(hipMemcpy(d_cubes.p, cubes, nq * sizeof(dcdf_cube), hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_lo.p, lower, nq * 8, hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_hi.p, upper, nq * 8, hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_sb.p, sb.data(), (nq + 1) * 4, hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_ib.p, ib.data(), (nq + 1) * 4, hipMemcpyHostToDevice));
+    K2R_HIP(hipMemcpy(d_wb.p, wb.data(), (nq + 1) * 4, hipMemcpyHostToDevice));
+    K2R_HIP(d_qs.alloc_pooled(ns * sizeof(WinQuery)));
+    K2R_HIP(d_items.alloc_pooled(ni * sizeof(SearchItem)));
+    K2R_HIP(d_witems.alloc_pooled(nw * sizeof(WinItem)));
+    K2R_HIP(d_sx.alloc_pooled(nw * sizeof(SearchExtra)));
+    K2R_HIP(d_wbits.alloc_pooled(nw * 512));  // (every word is written by the walk: nothing to clear)
+    K2R_HIP(d_counts.alloc(ni * 4));
+    K2R_HIP(d_offs.alloc(ni * 8));
+    const uint32_t nb = (uint32_t)((ni + kScanPer - 1) / kScanPer);
+    K2R_HIP(d_sums.alloc((size_t)nb * 8));
+    K2R_HIP(d_total.alloc(8));
+    K2R_HIP(d_qc.alloc(nq * 8));
+    K2R_HIP(d_qo.alloc(nq * 8));
+    EventPair ev;
+    K2R_HIP(ev.create());
+    const RasterGeom g{r->T, r->R, r->C, r->tile, r->cs, r->nti, r->ntj, 64u};
+    const uint32_t nw32 = (uint32_t)nw, ni32 = (uint32_t)ni, nq32 = (uint32_t)nq;
+    hipLaunchKernelGGL(k_raster_search_expand, dim3((nq32 + 255) / 256), dim3(256), 0, 0, d_cubes.as<dcdf_cube>(), d_lo.as<int64_t>(), d_hi.as<int64_t>(),
+                       d_sb.as<uint32_t>(), d_ib.as<uint32_t>(), d_wb.as<uint32_t>(), nq32, g, r->d_quirk.as<uint8_t>(), d_qs.as<WinQuery>(),
+                       d_items.as<SearchItem>(), d_witems.as<WinItem>(), d_sx.as<SearchExtra>());
+    K2R_HIP(hipEventRecord(ev.e0, 0));
+    if (r->all_narrow)
+        hipLaunchKernelGGL((k_window_wave2<4, false, true, int32_t>), dim3(std::min<uint32_t>((nw32 + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
+                           r->d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw32, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
+    else
+        hipLaunchKernelGGL((k_window_wave2<3, false, true>), dim3(std::min<uint32_t>((nw32 + 3) / 4, 256u * 16u)), dim3(256), 0, 0,
+                           r->d_refs.as<ChunkRef>(), d_witems.as<WinItem>(), nw32, d_wbits.p, (int32_t)DCDF_I64, d_sx.as<SearchExtra>());
+    hipLaunchKernelGGL(k_search_count, dim3((ni32 + 63) / 64), dim3(64), 0, 0, d_wbits.as<uint32_t>(), d_items.as<SearchItem>(), d_qs.as<WinQuery>(), ni32,
+                       d_counts.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, 0, d_counts.as<uint32_t>(), ni32, d_sums.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, 0, d_sums.as<uint64_t>(), nb, d_total.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, 0, d_counts.as<uint32_t>(), ni32, d_sums.as<uint64_t>(), d_offs.as<uint64_t>());
+    hipLaunchKernelGGL(k_raster_query_counts, dim3((nq32 + 255) / 256), dim3(256), 0, 0, d_ib.as<uint32_t>(), nq32, ni32, d_offs.as<uint64_t>(),
+                       d_total.as<uint64_t>(), d_qc.as<uint64_t>(), d_qo.as<uint64_t>());
+    K2R_HIP(hipGetLastError());
+    uint64_t total = 0;
+    K2R_HIP(hipMemcpy(&total, d_total.p, 8, hipMemcpyDeviceToHost));
+    K2R_HIP(hipMemcpy(counts, d_qc.p, nq * 8, hipMemcpyDeviceToHost));
+    K2R_HIP(hipMemcpy(offsets, d_qo.p, nq * 8, hipMemcpyDeviceToHost));
+    if (total > cap) return DCDF_ERR_CAPACITY;
+    const bool to_dev = out_mem == DCDF_MEM_DEVICE;
+    if (total > 0) {
+        if (!to_dev) K2R_HIP(d_out.alloc_pooled(total * 12));
+        hipLaunchKernelGGL(k_search_emit, dim3((ni32 + 63) / 64), dim3(64), 0, 0, d_qs.as<WinQuery>(), d_items.as<SearchItem>(), ni32,
+                           (const uint32_t*)nullptr, d_wbits.as<uint32_t>(), d_offs.as<uint64_t>(), to_dev ? out : d_out.as<uint32_t>());
+    }
+    K2R_HIP(hipEventRecord(ev.e1, 0));
+    K2R_HIP(hipGetLastError());
+    if (total > 0 && !to_dev) K2R_HIP(hipMemcpy(out, d_out.p, total * 12, hipMemcpyDeviceToHost));
+    else K2R_HIP(hipDeviceSynchronize());
+    float ms = 0.f;
+    K2R_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    if (kernel_ms) *kernel_ms = ms;
+    return DCDF_OK;
+}
+
 extern "C" int dcdf_raster_search_batch(const dcdf_raster* r, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper, size_t nq,
                                         uint32_t* out, size_t cap, int out_mem, uint64_t* counts, uint64_t* offsets, float* kernel_ms) {
     if (!r || !cubes || !lower || !upper || !counts || !offsets || nq == 0 || (!out && cap)) return DCDF_ERR_BAD_ARG;
     if (out_mem != DCDF_MEM_HOST && out_mem != DCDF_MEM_DEVICE) return DCDF_ERR_BAD_ARG;
+    // k = 2 chunks: pieces, items, counts, offsets and triples all stay on the device; other arities take the host-built form below
+    if (r->all_node && nq <= 0x7fffffffu && !std::getenv("K2R_SEARCH_DFS") && !std::getenv("K2R_RASTER_HOST"))
+        return raster_search_device(r, cubes, lower, upper, nq, out, cap, out_mem, counts, offsets, kernel_ms);
     std::vector<dcdf_chunk*> sch;
     std::vector<dcdf_cube> scube;
     std::vector<int64_t> slo, shi;
