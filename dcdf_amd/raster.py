@@ -59,7 +59,7 @@ class EncodedRaster:
         dtype = np.dtype(dtype)
         ms = C.c_float()
         if out_device_ptr is None:
-            vol = ((q[:, 1].astype(np.int64) - q[:, 0]) * (q[:, 3].astype(np.int64) - q[:, 2]) * (q[:, 5].astype(np.int64) - q[:, 4])).astype(np.uint64)
+            vol = np.abs((q[:, 1].astype(np.int64) - q[:, 0]) * (q[:, 3].astype(np.int64) - q[:, 2]) * (q[:, 5].astype(np.int64) - q[:, 4])).astype(np.uint64)  # (reversed bounds are reordered, geom.rs:83-103)
             off = np.zeros(len(q), dtype=np.uint64)
             if len(q) > 1:
                 off[1:] = np.cumsum(vol)[:-1]
@@ -83,7 +83,7 @@ class EncodedRaster:
         counts = np.zeros(len(q), dtype=np.uint64)
         offs = np.zeros(len(q), dtype=np.uint64)
         if cap is None:
-            cap = int(((q[:, 1].astype(np.int64) - q[:, 0]) * (q[:, 3].astype(np.int64) - q[:, 2]) * (q[:, 5].astype(np.int64) - q[:, 4])).sum())
+            cap = int(np.abs((q[:, 1].astype(np.int64) - q[:, 0]) * (q[:, 3].astype(np.int64) - q[:, 2]) * (q[:, 5].astype(np.int64) - q[:, 4])).sum())
         ms = C.c_float()
         trip = None if out_device_ptr else np.empty((max(cap, 1), 3), dtype=np.uint32)
         L.check(L.lib().dcdf_raster_search_batch(self._handle(), q.ctypes.data_as(C.POINTER(L.Cube)), C.c_void_p(lo.ctypes.data),

@@ -344,3 +344,37 @@ def test_native_raster_routing_matches_the_python_routing(dc, monkeypatch, host_
         ch.close()
     enc.close()
     buf.free()
+
+
+def test_raster_entry_points_reject_bad_input(dc):
+    """dcdf_raster_*: a chunk table that does not match the grid, cubes beyond the raster, a result buffer too small -- error
+    codes, not crashes (the reference panics at mmarray.rs:218-229)."""
+    import ctypes as C
+    from dcdf_amd import _lib as L, synth
+    from dcdf_amd.raster import EncodedRaster
+    a = synth.cells(0xDCDF0003, 0, 8, 0, 256, 0, 512, np.int32)
+    chunks = [dc.Chunk.build(np.ascontiguousarray(a[:, :, 256 * j:256 * j + 256])).data for j in range(2)]
+    hs = (C.c_void_p * 2)(*[c._h for c in chunks])
+    h = C.c_void_p()
+    shp = (C.c_uint32 * 3)(8, 256, 512)
+    assert L.lib().dcdf_raster_create(hs, C.c_size_t(2), shp, 128, 8, C.byref(h)) == -1      # DCDF_ERR_BAD_ARG: 2 x 4 tiles of 128, not 2 chunks
+    assert L.lib().dcdf_raster_create(hs, C.c_size_t(2), (C.c_uint32 * 3)(8, 256, 500), 256, 8, C.byref(h)) == -1  # second chunk is 256 wide, not 244
+    R = EncodedRaster((8, 256, 512), chunks, tile=256, chunk_size=8)
+    good = [(0, 8, 10, 20, 250, 262)]
+    flat, off, _ = R.fill_windows_flat(good, dtype=np.int32)
+    np.testing.assert_array_equal(flat.reshape(8, 10, 12), a[:, 10:20, 250:262])
+    for bad in [(0, 9, 0, 1, 0, 1), (0, 1, 0, 257, 0, 1), (0, 1, 0, 1, 0, 513)]:
+        with pytest.raises(L.DcdfError) as e:
+            R.fill_windows_flat([bad], dtype=np.int32)
+        assert e.value.code == -5  # DCDF_ERR_BOUNDS
+        with pytest.raises(L.DcdfError) as e:
+            R.search_flat([bad], [0], [1])
+        assert e.value.code == -5
+    with pytest.raises(L.DcdfError) as e:  # every cell matches, room for ten triples
+        R.search_flat(good, [-10 ** 9], [10 ** 9], cap=10)
+    assert e.value.code == -11  # DCDF_ERR_CAPACITY
+    trip, soff, cnt, _ = R.search_flat([(8, 0, 20, 10, 262, 250)], [10 ** 9], [-10 ** 9])   # reversed bounds everywhere (geom.rs:83-103)
+    assert int(cnt[0]) == 8 * 10 * 12
+    R.close()
+    for c in chunks:
+        c.close()
