@@ -378,3 +378,42 @@ def test_raster_entry_points_reject_bad_input(dc):
     R.close()
     for c in chunks:
         c.close()
+
+
+@pytest.mark.parametrize("k,tile", [(3, 81), (4, 64), (2, 300)])
+def test_raster_entry_points_other_arities_and_tiles(dc, k, tile):
+    """dcdf_raster_* over chunks that do not take the k = 2 node walk (k = 3, 4: the wave kernel on the chunk's 32-grid, search
+    by decode-and-test with host-built items) and over padded k = 2 tiles wider than one 64-piece: windows and matches against
+    the raw raster."""
+    from dcdf_amd import build_batch
+    from dcdf_amd.raster import EncodedRaster
+    rng = np.random.default_rng(100 + k)
+    shape = (11, 2 * tile + 17, tile + 40)
+    cs = 4
+    full = (rng.integers(0, 50, size=shape[1:])[None] + (rng.random(shape) < 0.05) * rng.integers(-200, 200, size=shape)).astype(np.int32)
+    full[7] = full[6]
+    grid = EncodedRaster.chunk_grid(shape, tile, cs)
+    built = build_batch([np.ascontiguousarray(full[t0:t1, r0:r1, c0:c1]) for t0, t1, r0, r1, c0, c1 in grid], k=k)
+    chunks = [b.data for b in built]
+    R = EncodedRaster(shape, chunks, tile=tile, chunk_size=cs)
+    cubes = [(0, shape[0], 0, shape[1], 0, shape[2])]
+    for _ in range(60):
+        t0 = int(rng.integers(0, shape[0])); t1 = min(shape[0], t0 + int(rng.integers(1, 8)))
+        r0 = int(rng.integers(0, shape[1])); r1 = min(shape[1], r0 + int(rng.integers(1, 150)))
+        c0 = int(rng.integers(0, shape[2])); c1 = min(shape[2], c0 + int(rng.integers(1, 150)))
+        cubes.append((t0, t1, r0, r1, c0, c1))
+    flat, off, _ = R.fill_windows_flat(cubes, dtype=np.int64)
+    for q, c in enumerate(cubes):
+        exp = full[c[0]:c[1], c[2]:c[3], c[4]:c[5]]
+        np.testing.assert_array_equal(flat[int(off[q]):int(off[q]) + exp.size].reshape(exp.shape), exp)
+    lo = rng.integers(-100, 100, size=len(cubes))
+    hi = lo + rng.integers(0, 60, size=len(cubes))
+    trip, soff, cnt, _ = R.search_flat(cubes, lo, hi)
+    for q, c in enumerate(cubes):
+        got = set(map(tuple, trip[int(soff[q]):int(soff[q]) + int(cnt[q])].tolist()))
+        sub = full[c[0]:c[1], c[2]:c[3], c[4]:c[5]]
+        want = set((int(a) + c[0], int(b) + c[2], int(d) + c[4]) for a, b, d in zip(*np.nonzero((sub >= lo[q]) & (sub <= hi[q]))))
+        assert len(got) == int(cnt[q]) and got == want, q
+    R.close()
+    for ch in chunks:
+        ch.close()
