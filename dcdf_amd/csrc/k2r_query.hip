@@ -510,29 +510,46 @@ struct KidsT {
 };
 typedef KidsT<int64_t> Kids;
 // the four children of node p (log.rs:392-505 / snapshot.rs:281-299 for all of i, j at once)
+// bits i .. i + 3 of a bitmap (bit i = 8), bits beyond its words read as 0 like gbm_get; two loads, no branch
+__device__ __forceinline__ uint32_t gbm_get4(gbytes b, const BmDesc& d, uint32_t i) {
+    const uint32_t nw = (d.len + 31) / 32, w = i >> 5, sh = i & 31u;
+    const uint32_t w0 = w < nw ? w : 0u, w1 = w + 1 < nw ? w + 1 : 0u;
+    uint32_t x = gld_be32(b + d.words_off + 4 * w0), y = gld_be32(b + d.words_off + 4 * w1);
+    x = w < nw ? x : 0u;
+    y = w + 1 < nw ? y : 0u;
+    return (uint32_t)(((((uint64_t)x << 32) | y) >> (60 - sh)) & 15u);
+}
 template <class V>
 __device__ __forceinline__ void expand4(gbytes b, const TreeRef& S, const DacDesc& Sfull, const TreeRef& L, const DacDesc& Lfull,
                                         const NodeStT<V>& p, KidsT<V>* o) {
+    // Every read below is unconditional (a side that has nothing to read reads index 0 and drops the result): behind
+    // `if (has_t)` / `if (has_s)` / per-child branches the log's chain of dependent loads, the snapshot's and up to four eqB
+    // reads ran one after the other; this way they are in flight together.
     const bool has_t = p.bt != WQ_NONE, has_s = p.bs != WQ_NONE;
-    V vt[4] = {p.mt, p.mt, p.mt, p.mt}, vs[4] = {0, 0, 0, 0};
-    uint32_t tt = 0, ts = 0, rt = 0, rs = 0;  // T nibbles (bit c = 8 >> c) and rank of the first child
-    bool cells_t = true, cells_s = true;      // the children are beyond T: cells
-    if (has_t) {
-        dac4(b, L, Lfull, p.bt, vt);
-        cells_t = p.bt >= L.T.len;
-        if (!cells_t) rt = rank_nib(b, L.T, p.bt, &tt);
-    }
-    if (has_s) {
-        dac4(b, S, Sfull, p.bs, vs);
-        cells_s = p.bs >= S.T.len;
-        if (!cells_s) rs = rank_nib(b, S.T, p.bs, &ts);
+    const bool cells_t = !has_t || p.bt >= L.T.len, cells_s = !has_s || p.bs >= S.T.len;  // the children are beyond T: cells
+    V dt[4], ds[4];
+    dac4(b, L, Lfull, has_t ? p.bt : 0u, dt);
+    dac4(b, S, Sfull, has_s ? p.bs : 0u, ds);
+    uint32_t tt = 0, ts = 0;  // T nibbles (bit c = 8 >> c) and rank of the first child
+    uint32_t rt = rank_nib(b, L.T, cells_t ? 0u : p.bt, &tt), rs = rank_nib(b, S.T, cells_s ? 0u : p.bs, &ts);
+    if (cells_t) { tt = 0; rt = 0; }
+    if (cells_s) { ts = 0; rs = 0; }
+    // eqB bits of the children with T = 0 (log.rs:452-467): child c's is eqB[p.bt + c - rank(T, p.bt + c)] = the (zeros among the
+    // children before c)-th bit from eqB[p.bt - rt] on -- four consecutive bits at most
+    const uint32_t eq4 = gbm_get4(b, L.E, cells_t ? 0u : p.bt - rt);
+    V vt[4], vs[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        vt[c] = has_t ? dt[c] : p.mt;
+        vs[c] = has_s ? ds[c] : (V)0;
     }
     o->fill = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const bool bit_t = (tt >> (3 - c)) & 1u, bit_s = (ts >> (3 - c)) & 1u;
         const bool leaf_t = !has_t || cells_t || !bit_t, leaf_s = !has_s || cells_s || !bit_s;
-        const uint32_t rtc = rt + popc32(tt >> (4 - c)), rsc = rs + popc32(ts >> (4 - c));  // rank(T, base + c)
+        const uint32_t before_t = popc32(tt >> (4 - c));
+        const uint32_t rtc = rt + before_t, rsc = rs + popc32(ts >> (4 - c));  // rank(T, base + c)
         const V mt_ = vt[c], ms_ = has_s ? p.ms - vs[c] : p.ms;
         o->val[c] = mt_ + ms_;
         NodeStT<V>& n = o->st[c];
@@ -545,7 +562,8 @@ __device__ __forceinline__ void expand4(gbytes b, const TreeRef& S, const DacDes
         } else if (leaf_s) {
             n.bt = 1 + rtc * 4;
         } else if (leaf_t) {
-            if (has_t && !cells_t && !gbm_get(b, L.E, p.bt + c - rtc)) o->fill |= 1u << c;  // uniform, not "equal" (log.rs:452-467)
+            const bool eq = (eq4 >> (3 - ((uint32_t)c - before_t))) & 1u;
+            if (has_t && !cells_t && !eq) o->fill |= 1u << c;  // uniform, not "equal" (log.rs:452-467)
             else n.bs = 1 + rsc * 4;
         } else {
             n.bt = 1 + rtc * 4;
@@ -798,39 +816,89 @@ k_window_wave2(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ 
 #ifdef K2R_DIAG_NO_FINAL
         hi = lo;  // (diagnostic build: time of the upper levels alone; results are wrong)
 #endif
-        for (uint32_t base = lo; base < hi; base += 64) {
+        // A lane expands one node of side 4 into its quads.  A quad of one value is written at once; the OPEN quads (two Dac
+        // reads each, the expensive part) of all the lanes are compacted into the free tail of the frontier and then taken one
+        // per lane: typically a third of the quads are open, so a lane-per-node loop over all four would spend two thirds of
+        // its Dac reads on masked-off lanes.
+        auto put_quad = [&](uint32_t cr, uint32_t cc, const V (&v)[4]) {
+            const bool in = cr >= wtop && cr + 2 <= wbot && cc >= wleft && cc + 2 <= wright;
+            if (DENSE64 && !SEARCH && in) {  // two cells of a row per store (16 bytes, any 8-byte alignment)
+                typedef long long ll2 __attribute__((ext_vector_type(2)));
+                typedef ll2 __attribute__((aligned(8))) ll2u;
+                int64_t* const o0 = (int64_t*)out + (obase + (int64_t)(cr * osr + cc));
+                *(__attribute__((address_space(1))) ll2u*)o0 = ll2{(long long)v[0], (long long)v[1]};
+                *(__attribute__((address_space(1))) ll2u*)(o0 + osr) = ll2{(long long)v[2], (long long)v[3]};
+                return;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t r = cr + (uint32_t)(e >> 1), cl = cc + (uint32_t)(e & 1);
+                if (in || (r >= wtop && r < wbot && cl >= wleft && cl < wright)) put(r, cl, v[e]);
+            }
+        };
+        const uint32_t room = ((uint32_t)WQ2_CAP - hi) / 4u;            // nodes per round whose quads fit the tail
+        const uint32_t per_round = room < 64u ? room : 64u;
+        for (uint32_t base = lo; base < hi; base += (per_round ? per_round : 64u)) {
             const uint32_t n = base + (uint32_t)lane;
-            if (n >= hi) continue;
-            const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
-            const uint32_t po = q.org[n], pr = po >> 16, pc = po & 0xffffu;
+            const bool live = n < hi && (per_round == 0 || (uint32_t)lane < per_round);
             Kids kd;
-            expand4(gb, S, SD.mx, L, D.mx, p, &kd);
-            const bool inside = pr >= wtop && pr + 4 <= wbot && pc >= wleft && pc + 4 <= wright;  // no clipping needed
+            kd.fill = 0;
+            uint32_t pr = 0, pc = 0, openm = 0;
+            if (live) {
+                const NodeSt p{q.it[n], q.is[n], q.mt[n], q.ms[n]};
+                const uint32_t po = q.org[n];
+                pr = po >> 16;
+                pc = po & 0xffffu;
+                expand4(gb, S, SD.mx, L, D.mx, p, &kd);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const uint32_t cr = pr + 2u * (uint32_t)(c >> 1), cc = pc + 2u * (uint32_t)(c & 1);
-                if (!inside && !(cr < wbot && cr + 2 > wtop && cc < wright && cc + 2 > wleft)) continue;
-                V v[4] = {kd.val[c], kd.val[c], kd.val[c], kd.val[c]};
-                if (!((kd.fill >> c) & 1u)) {
-                    Kids g;
-                    expand4(gb, S, SD.mx, L, D.mx, kd.st[c], &g);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = g.val[e];
-                }
-                if (DENSE64 && !SEARCH && inside) {  // two cells of a row per store (16 bytes, any 8-byte alignment)
-                    typedef long long ll2 __attribute__((ext_vector_type(2)));
-                    typedef ll2 __attribute__((aligned(8))) ll2u;
-                    int64_t* const o0 = (int64_t*)out + (obase + (int64_t)(cr * osr + cc));
-                    *(__attribute__((address_space(1))) ll2u*)o0 = ll2{(long long)v[0], (long long)v[1]};
-                    *(__attribute__((address_space(1))) ll2u*)(o0 + osr) = ll2{(long long)v[2], (long long)v[3]};
-                    continue;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const uint32_t r = cr + (uint32_t)(e >> 1), cl = cc + (uint32_t)(e & 1);
-                    if (inside || (r >= wtop && r < wbot && cl >= wleft && cl < wright)) put(r, cl, v[e]);
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t cr = pr + 2u * (uint32_t)(c >> 1), cc = pc + 2u * (uint32_t)(c & 1);
+                    if (!(cr < wbot && cr + 2 > wtop && cc < wright && cc + 2 > wleft)) continue;  // outside the item
+                    if ((kd.fill >> c) & 1u) {
+                        const V v[4] = {kd.val[c], kd.val[c], kd.val[c], kd.val[c]};
+                        put_quad(cr, cc, v);
+                    } else {
+                        openm |= 1u << c;
+                    }
                 }
             }
+            if (per_round == 0) {  // (no room in the frontier's tail: the lane finishes its own quads)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if ((openm >> c) & 1u) {
+                        Kids g;
+                        expand4(gb, S, SD.mx, L, D.mx, kd.st[c], &g);
+                        put_quad(pr + 2u * (uint32_t)(c >> 1), pc + 2u * (uint32_t)(c & 1), g.val);
+                    }
+                continue;
+            }
+            const uint32_t np = popc32(openm);
+            const uint32_t inc = GpuExecScan::incl(np);
+            uint32_t pos = hi + inc - np;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if ((openm >> c) & 1u) {
+                    q.it[pos] = kd.st[c].bt; q.is[pos] = kd.st[c].bs; q.mt[pos] = kd.st[c].mt; q.ms[pos] = kd.st[c].ms;
+                    q.org[pos] = ((pr + 2u * (uint32_t)(c >> 1)) << 16) | (pc + 2u * (uint32_t)(c & 1));
+                    pos++;
+                }
+            const uint32_t nopen = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t kb = 0; kb < nopen; kb += 64) {  // one open quad per lane: its four cells (expand4 at the cell level:
+                const uint32_t m = kb + (uint32_t)lane;     // log.rs:404-420, snapshot.rs:281-299)
+                if (m < nopen) {
+                    const NodeSt k{q.it[hi + m], q.is[hi + m], q.mt[hi + m], q.ms[hi + m]};
+                    const uint32_t ko = q.org[hi + m];
+                    const bool ht = k.bt != WQ_NONE, hs = k.bs != WQ_NONE;
+                    V vt[4], vs[4], v[4];
+                    dac4(gb, L, D.mx, ht ? k.bt : 0u, vt);  // (both unconditional: the two chains of loads are in flight together)
+                    dac4(gb, S, SD.mx, hs ? k.bs : 0u, vs);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (ht ? vt[e] : k.mt) + (hs ? k.ms - vs[e] : k.ms);
+                    put_quad(ko >> 16, ko & 0xffffu, v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         flush_bits();
         __builtin_amdgcn_wave_barrier();
