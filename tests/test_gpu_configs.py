@@ -417,3 +417,33 @@ def test_raster_entry_points_other_arities_and_tiles(dc, k, tile):
     R.close()
     for ch in chunks:
         ch.close()
+
+
+def test_calls_from_several_host_threads(dc):
+    """the entry points may be called from several host threads (ctypes drops the GIL inside a call): four
+    threads build chunks through the host-buffer entry point, open them, run windows / searches / points and assemble a
+    superchunk at the same time; every result equals the one a single thread gets."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dcdf_amd import synth, build_batch, Superchunk
+
+    def work(seed):
+        a = synth.cells(0xDCDF0100 + seed, 0, 12, 0, 256, 0, 256, np.int32)
+        built = build_batch([a, a[:, :100, :77], a.astype(np.int64) * 2 + 1])
+        datas = [b.data.write_to() for b in built]
+        ch = built[0].data
+        win = ch.fill_window(dc.Cube(2, 9, 10, 200, 30, 250))
+        hits = sorted(map(tuple, np.asarray(ch.iter_search(dc.Cube(0, 12, 0, 256, 0, 256), 0, 40)).tolist()))
+        pts = [ch.get(t, 5 * t, 250 - t) for t in range(12)]
+        sc = Superchunk.build(np.ascontiguousarray(np.tile(a, (1, 2, 2))[:8]), [1, 8])
+        for b in built:
+            b.data.close()
+        return datas, win.tobytes(), hits, pts, sorted(sc.objects.items()), sc.size
+
+    seeds = list(range(8))
+    ref = [work(s) for s in seeds[:4]]
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(work, seeds[:4] * 3))
+    for i, g in enumerate(got):
+        assert g == ref[i % 4], i
+    a0 = synth.cells(0xDCDF0100, 0, 12, 0, 256, 0, 256, np.int32)
+    assert ref[0][0][0] == O.chunk_build(a0) and ref[0][1] == np.ascontiguousarray(a0[2:9, 10:200, 30:250]).tobytes()
