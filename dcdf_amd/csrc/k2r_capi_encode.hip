@@ -528,7 +528,7 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
                          i, d[0]);
         }
     // Tiles whose slot was too small: re-encode them alone into worst-case slots (rare; not timed).  Tiles whose
-    // speculative halves did not splice: re-encode them whole (which may then turn out too big for the slot: second pass).
+    // speculative parts did not splice: re-encode them whole (which may then turn out too big for the slot: second pass).
     for (int pass = 0; pass < 2; pass++) {
     std::vector<std::vector<uint32_t>> again(e->classes.size());
     bool any = false, unsplit = false;

@@ -32,7 +32,7 @@ enum : int32_t {
     ST_UNSUPPORTED = -8,
     ST_OUT_CAPACITY = -100,  // internal: output slot too small, host retries with a bigger slot
     ST_INTERNAL = -101,      // an internal consistency guard tripped (bug); TileResult.dbg has the record
-    ST_RESPLIT = -102,       // internal: a chunk encoded as two speculative halves whose assumption failed; the host re-runs it whole
+    ST_RESPLIT = -102,       // internal: a chunk encoded in speculative parts whose assumption failed; the host re-runs it whole
 };
 
 enum : int32_t { ENC_I32 = 4, ENC_I64 = 8, ENC_F32 = 32, ENC_F64 = 64 };

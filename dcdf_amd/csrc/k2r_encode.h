@@ -1611,7 +1611,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         bool do_patch = false;
         if (as_snapshot) {
             if (have_s) {  // close the open block (chunk.rs:63-70)
-                if (blk_hdr == NO_HDR) carry = blk_count;  // the inherited block: stitch_halves() patches its count byte
+                if (blk_hdr == NO_HDR) carry = blk_count;  // the inherited block: k_stitch patches its count byte
                 else {
                     do_patch = true;
                     hdr_patch_off = blk_hdr;

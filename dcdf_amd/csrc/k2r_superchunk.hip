@@ -374,7 +374,7 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             if (rc != DCDF_OK) return rc;
             if (st != DCDF_OK) return st;
         }
-        // SHA-256 of a 1.4 MB object is one serial chain on one lane (≈ 150 ms for the 256 objects of a 4096^2 level): it runs on
+        // SHA-256 of a 1.4 MB object is one serial chain on one lane (≈ 140 ms for the 256 objects of a 4096^2 level): it runs on
         // the session's stream from a helper thread while this thread gathers the bytes (own stream) and frames the objects
         std::vector<uint8_t> dig(nc * 32);
         int sha_rc = DCDF_OK;

@@ -266,7 +266,7 @@ def test_property_random_tiles(instants, rows, cols, seed, kind, dtype):
 
 
 def test_speculative_halves():
-    """A chunk encoded as two work items (k2r_encode.h "speculative halves", spliced as k_stitch does): byte-identical to the
+    """A chunk encoded as two or more work items (k2r_encode.h "speculative parts", spliced as k_stitch does): byte-identical to the
     sequential encode whenever the first half holds a single block; reported as -102 (re-encode whole) when a block boundary
     falls into the first half; errors of either half surface."""
     L = S.lib()
