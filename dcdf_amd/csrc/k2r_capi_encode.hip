@@ -501,6 +501,51 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
         for (int k = 0; k < NPROF; k++)
             std::fprintf(stderr, "k2r-prof %-18s %14llu cyc %5.1f%%\n", names[k], (unsigned long long)acc[k],
                          tot ? 100.0 * (double)acc[k] / (double)tot : 0.0);
+#ifdef K2R_PROFILE
+        // Per WAVE (k2r_exec.h): cycles of a wave's own work and cycles it was parked at barriers, per phase, summed over all
+        // tiles.  "max" is the busiest wave's work -- what the phase costs the workgroup --, "mean" the average wave's; the
+        // difference is barrier wait caused by imbalance, and "wait" is what the average wave actually spent parked.
+        {
+            static uint64_t w[16][NPROF][2];
+            std::memset(w, 0, sizeof(w));
+            for (size_t i = 0; i < n; i++)
+                for (int v = 0; v < 16; v++)
+                    for (int k = 0; k < NPROF; k++) {
+                        w[v][k][0] += e->results[i].pw[v][k][0];
+                        w[v][k][1] += e->results[i].pw[v][k][1];
+                    }
+            int nw = 0;
+            for (int v = 0; v < 16; v++) {
+                uint64_t t = 0;
+                for (int k = 0; k < NPROF; k++) t += w[v][k][0] + w[v][k][1];
+                if (t) nw = v + 1;
+            }
+            uint64_t insts = 0;
+            for (size_t i = 0; i < n; i++) insts += e->results[i].snapshots + e->results[i].logs;
+            double all = 0;
+            for (int k = 0; k < NPROF; k++)
+                for (int v = 0; v < nw; v++) all += (double)(w[v][k][0] + w[v][k][1]);
+            all /= nw ? nw : 1;
+            std::fprintf(stderr, "k2r-pw %d waves, %llu chunk-instants, %.0f cycles per chunk-instant and wave (work + wait)\n", nw,
+                         (unsigned long long)insts, insts ? all / (double)insts : 0.0);
+            std::fprintf(stderr, "k2r-pw %-24s %9s %9s %9s %9s %7s   (cycles per chunk-instant)\n", "phase", "work-mean", "work-max", "work-w0",
+                         "wait-mean", "share");
+            for (int k = 0; k < NPROF; k++) {
+                double mean = 0, mx = 0, wait = 0;
+                for (int v = 0; v < nw; v++) {
+                    mean += (double)w[v][k][0];
+                    wait += (double)w[v][k][1];
+                    mx = std::max(mx, (double)w[v][k][0]);
+                }
+                if (mean + wait == 0) continue;
+                mean /= nw;
+                wait /= nw;
+                const double d = insts ? (double)insts : 1.0;
+                std::fprintf(stderr, "k2r-pw %-24s %9.0f %9.0f %9.0f %9.0f %6.1f%%\n", names[k], mean / d, mx / d, (double)w[0][k][0] / d, wait / d,
+                             all ? 100.0 * (mean + wait) / all : 0.0);
+            }
+        }
+#endif
         // per-tile totals: how uneven are the chunks?  (cycles per instant, logs that did not come from the stash)
         std::vector<double> per;
         uint64_t logs = 0, stash = 0;

@@ -77,6 +77,9 @@ struct TileResult {
     uint32_t carry_count;  // continuation: instants of the inherited block (when it closed, or at the end if it never did)
     uint32_t _pad2;
     uint64_t prof[NPROF];  // shader-clock cycles per phase (only filled by -DK2R_PROFILE diagnostic builds)
+#ifdef K2R_PROFILE
+    uint64_t pw[16][NPROF][2];  // per wave and phase: [0] cycles of its own work, [1] cycles parked at barriers (k2r_exec.h)
+#endif
 };
 
 K2R_HD uint32_t popc32(uint32_t x) { return (uint32_t)__builtin_popcount(x); }

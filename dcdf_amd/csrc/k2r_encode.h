@@ -549,7 +549,12 @@ struct EncPool {
     static constexpr int POOL_L1 = 4 * C::NBLK;                 // word offset of L1 (16*NBLK u16 = 8*NBLK words)
     static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
     static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
-    static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? 4900 : 0);  // sidelen 256: LDS filled to 160 KB
+#ifdef K2R_PROFILE
+    static constexpr int POOLFILL = 4900 - 16 * NPROF * 4;  // (the per-wave cycle sums of the diagnostic build live in LDS too)
+#else
+    static constexpr int POOLFILL = 4900;
+#endif
+    static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? POOLFILL : 0);  // sidelen 256: LDS filled to 160 KB
     // The stash's two record kinds have fixed shares of the pool (I records grow up from word 0, Q records down from POOLW);
     // records beyond a share go to a per-workgroup overflow area in global scratch (L2), so an instant with unusually many
     // records -- a snapshot with forced-constant 64x64 blocks makes every quad under them internal -- still takes the stash
@@ -594,6 +599,9 @@ struct EncShared : EncPool<C> {
     uint32_t work;
     uint32_t fault[6];  // [0] = count, [1..5] = first record (code, instant, tid, value, limit)
     uint64_t prof[NPROF], prof_last;  // -DK2R_PROFILE only
+#ifdef K2R_PROFILE
+    uint64_t pw[16][NPROF][2];
+#endif
 };
 
 // ---- internal consistency guard --------------------------------------------------------------------
@@ -1027,7 +1035,14 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
     });
     if (cap < 7 && !cont) status = ST_OUT_CAPACITY;
 #ifdef K2R_PROFILE
-    if (!EX::kSim) ex.par([&](int tid, EncRegs&) { if (tid == 0) sh.prof_last = clock64(); });
+    if (!EX::kSim) {
+        ex.par([&](int tid, EncRegs&) {
+            if (tid == 0) sh.prof_last = clock64();
+            if ((tid & 63) == 0)
+                for (int k = 0; k < NPROF; k++) sh.pw[tid >> 6][k][0] = sh.pw[tid >> 6][k][1] = 0;
+        });
+        ex.pw_start();
+    }
 #endif
 
     // the compact copy of instant `from` (the open block's snapshot) for the logs that follow
@@ -2087,6 +2102,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             for (int i = 0; i < 6; i++) res->dbg[i] = sh.fault[i];
             for (int i = 0; i < NPROF; i++) res->prof[i] = sh.prof[i];
         }
+#ifdef K2R_PROFILE
+        if (!EX::kSim && (tid & 63) == 0)
+            for (int k = 0; k < NPROF; k++) {
+                res->pw[tid >> 6][k][0] = sh.pw[tid >> 6][k][0];
+                res->pw[tid >> 6][k][1] = sh.pw[tid >> 6][k][1];
+            }
+#endif
     });
 }
 

@@ -28,11 +28,43 @@ struct GpuExec {
 
     __device__ GpuExec(SH& s) : sh(s), tid((int)threadIdx.x) {}
 
+#ifdef K2R_PROFILE
+    // Diagnostic builds: every WAVE keeps two running sums between stamps -- cycles it spent running its own code ("work") and
+    // cycles it spent parked at workgroup barriers ("wait": the slowest wave of the phase sets it) -- read with s_memtime on
+    // both sides of every barrier.  stamp(k) adds them to the wave's own row of sh.pw (lane 0 writes; no other wave touches the
+    // row).  Per phase, max-over-waves of "work" is the critical path and mean-over-waves the average load; their difference
+    // is what the phase loses to imbalance.
+    uint64_t pw_last = 0, pw_work = 0, pw_wait = 0;
+    __device__ __forceinline__ void pw_before() {
+        const uint64_t t = __builtin_amdgcn_s_memtime();
+        pw_work += t - pw_last;
+        pw_last = t;
+    }
+    __device__ __forceinline__ void pw_after() {
+        const uint64_t t = __builtin_amdgcn_s_memtime();
+        pw_wait += t - pw_last;
+        pw_last = t;
+    }
+    __device__ __forceinline__ void pw_start() { pw_last = __builtin_amdgcn_s_memtime(); pw_work = pw_wait = 0; }
+#else
+    __device__ __forceinline__ void pw_before() {}
+    __device__ __forceinline__ void pw_after() {}
+    __device__ __forceinline__ void pw_start() {}
+#endif
+
     // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits (vmcnt(0)) for every global
     // store of the wave to be acknowledged by L2 -- microseconds per phase here, for bytes nobody in the workgroup
     // reads back.  Phases that DO hand global data to other threads use barrier_global().
-    __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-    __device__ __forceinline__ void barrier_global() { __syncthreads(); }
+    __device__ __forceinline__ void lds_barrier() {
+        pw_before();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        pw_after();
+    }
+    __device__ __forceinline__ void barrier_global() {
+        pw_before();
+        __syncthreads();
+        pw_after();
+    }
 
     // Hand-off of global data to ANOTHER workgroup (the shared snapshot copy of a chunk encoded in parts, k2r_encode.h): the
     // producer's waves have drained their stores (barrier_global), one lane writes the XCD's L2 back and sets the flag;
@@ -86,6 +118,12 @@ struct GpuExec {
             sh.prof[k] += t - sh.prof_last;
             sh.prof_last = t;
         }
+        pw_before();  // the cycles since the last barrier are this wave's own work
+        if ((tid & 63) == 0) {
+            sh.pw[tid >> 6][k][0] += pw_work;
+            sh.pw[tid >> 6][k][1] += pw_wait;
+        }
+        pw_work = pw_wait = 0;
 #else
         (void)k;
 #endif

@@ -18,7 +18,6 @@ node encodings (dataset.rs:386-640) belong to the storage layer that is out of s
 that state by the SHA-256 of its canonical description, not by the reference's Dataset-node CID.
 
 No IPFS, no LRU cache: `Resolver` owns a dict."""
-import functools
 import hashlib
 import struct
 
@@ -29,7 +28,7 @@ from .chunk import Chunk, Cube
 from .superchunk import Superchunk
 
 NODE_LINKS, NODE_MMSTRUCT3, NODE_SPAN, NODE_SUBCHUNK, NODE_SUPERCHUNK = 1, 2, 3, 4, 5
-_PRIVATE = object()
+_FACTORY_KEY = object()
 
 
 class MMEncoding:  # py-dcdf __init__.py:8-29
@@ -170,23 +169,23 @@ class Resolver:
 
 class Coordinate:  # py-dcdf __init__.py:150-243
     def __init__(self, inner=None, private=None):
-        if private is not _PRIVATE:
-            raise RuntimeError("Please instantiate Coordinate using one of the constructor class methods like 'range' or 'time'")
+        if private is not _FACTORY_KEY:
+            raise RuntimeError("Coordinate objects come from Coordinate.time(...) or Coordinate.range(...)")
         self.name, self.kind, self.start, self.step, self.steps, self._dtype = inner
 
     @classmethod
     def time(cls, name, start, step):
         if isinstance(start, np.datetime64):
-            start = int((start - np.datetime64(0, "s")).item().total_seconds())
+            start = int(start.astype("datetime64[s]").astype(np.int64))
         if isinstance(step, np.timedelta64):
-            step = int(step.item().total_seconds())
-        return cls((name, "time", int(start), int(step), None, np.datetime64), _PRIVATE)
+            step = int(step / np.timedelta64(1, "s"))
+        return cls((name, "time", int(start), int(step), None, np.datetime64), _FACTORY_KEY)
 
     @classmethod
     def range(cls, name, start, step, steps, dtype=np.float64):
         if dtype not in (np.int32, np.int64, np.float32, np.float64):
-            raise ValueError(f"unsupported dtype for Coordinate {dtype}")
-        return cls((name, "range", start, step, int(steps), dtype), _PRIVATE)
+            raise ValueError("a range Coordinate holds int32, int64, float32 or float64 values, not %r" % (dtype,))
+        return cls((name, "range", start, step, int(steps), dtype), _FACTORY_KEY)
 
     @property
     def dtype(self):
@@ -202,12 +201,15 @@ class Coordinate:  # py-dcdf __init__.py:150-243
             return np.array([self.get(i) for i in range(start, end)], dtype="datetime64[s]")
         return (self.start + self.step * np.arange(start, end)).astype(self._dtype)
 
-    def __getitem__(self, i):
-        if isinstance(i, slice):
-            if i.step is not None:
-                raise ValueError("step not supported for slice")
-            return self.slice(0 if i.start is None else i.start, len(self) if i.stop is None else i.stop)
-        return self.get(i)
+    def __getitem__(self, key):
+        """One coordinate value for an integer, an array of them for `a:b` (open ends allowed; strides are not)."""
+        if not isinstance(key, slice):
+            return self.get(key)
+        if key.step not in (None, 1):
+            raise ValueError("a Coordinate can only be sliced with stride 1, got %r" % (key.step,))
+        first = key.start if key.start is not None else 0
+        last = key.stop if key.stop is not None else len(self)  # (an unbounded time axis needs an explicit stop)
+        return self.slice(first, last)
 
     def __len__(self):
         if self.kind == "time":
@@ -217,8 +219,8 @@ class Coordinate:  # py-dcdf __init__.py:150-243
 
 class Variable:  # py-dcdf __init__.py:246-336 over dataset.rs:642-986
     def __init__(self, inner=None, private=None):
-        if private is not _PRIVATE:
-            raise RuntimeError("Variable cannot be instantiated")
+        if private is not _FACTORY_KEY:
+            raise RuntimeError("Variable objects come from Dataset.add_variable(...)")
         (self.name, self._round, self.span_size, self.chunk_size, self._k2_levels, self.encoding, self.cid, self._resolver) = inner
 
     # ---- what py-dcdf exposes -------------------------------------------------------------------------------------------
@@ -279,37 +281,40 @@ class Variable:  # py-dcdf __init__.py:246-336 over dataset.rs:642-986
             self._route_search(cid, a0, a1, top, bottom, left, right, lower, upper, start + o0 - a0, 0, 0, hits)
         return np.array(sorted(hits), dtype=np.int64).reshape(-1, 3)
 
-    def __getitem__(self, indices):  # py-dcdf __init__.py:284-336, rule for rule
-        indices = [indices] if not isinstance(indices, tuple) else list(indices)
-        n_indices = len(indices)
-        if n_indices > 3:
-            raise IndexError(f"too many indices for array: array is 3-dimensional, but {len(indices)} were indexed")
-        while len(indices) < 3:
-            indices.append(slice(0, None))
-        fixed = []
-        for index, stop in zip(indices, self.shape):
-            if _is_int(index):
-                fixed.append(index)
-                continue
-            if index.start is None:
-                index = slice(0, index.stop)
-            if index.stop is None:
-                index = slice(index.start, stop)
-            fixed.append(index)
-        instant, row, col = fixed
-        scalars = tuple(map(_is_int, fixed))
+    def __getitem__(self, key):
+        """NumPy-style basic indexing with up to three integers / unit-stride slices; the answer is lazy (`.data` decodes).
+        Every axis is first reduced to a half-open range plus a "drop this axis" mark; the pattern of marks then picks the
+        cheapest query: a point, a cell's time series, or a window whose marked axes are squeezed out."""
+        axes = key if isinstance(key, tuple) else (key,)
+        if len(axes) > 3:
+            raise IndexError("a Variable has 3 axes (instant, row, col); %d indices were given" % len(axes))
+        lo, hi, drop = [], [], []
+        for axis, extent in enumerate(self.shape):
+            ix = axes[axis] if axis < len(axes) else slice(None)
+            if isinstance(ix, (int, np.integer)):
+                at = int(ix) + (extent if ix < 0 else 0)
+                lo.append(at)
+                hi.append(at + 1)
+                drop.append(True)
+            elif isinstance(ix, slice):
+                a, b, step = ix.indices(extent)
+                if step != 1:
+                    raise IndexError("axis %d: only unit-stride slices are supported" % axis)
+                lo.append(a)
+                hi.append(max(a, b))
+                drop.append(False)
+            else:
+                raise IndexError("axis %d: cannot index with %r" % (axis, type(ix).__name__))
 
-        def realize():
-            if all(scalars):
-                return self.get(instant, row, col)
-            if scalars == (False, True, True):
-                return self.cell(instant.start, instant.stop, row, col)
-            i, r, c = map(_as_slice, fixed)
-            array = self.window(i.start, i.stop, r.start, r.stop, c.start, c.stop)
-            mask = tuple(0 if s else slice(None, None) for s in scalars[:n_indices])
-            return array.__getitem__(mask[0] if len(mask) == 1 else mask)
+        def decode():
+            if drop == [True, True, True]:
+                return self.get(lo[0], lo[1], lo[2])
+            if drop == [False, True, True]:
+                return self.cell(lo[0], hi[0], lo[1], lo[2])
+            block = self.window(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+            return block.reshape([n for n, d in zip(block.shape, drop) if not d])
 
-        return _Slice(realize)
+        return _Lazy(decode)
 
     # ---- routing ----------------------------------------------------------------------------------------------------------
     def _root(self):
@@ -410,7 +415,7 @@ class Variable:  # py-dcdf __init__.py:246-336 over dataset.rs:642-986
 
     # ---- growth: Variable::append and friends (dataset.rs:834-986) -----------------------------------------------------
     def _with_cid(self, cid):
-        return Variable((self.name, self._round, self.span_size, self.chunk_size, self._k2_levels, self.encoding, cid, self._resolver), _PRIVATE)
+        return Variable((self.name, self._round, self.span_size, self.chunk_size, self._k2_levels, self.encoding, cid, self._resolver), _FACTORY_KEY)
 
     def _node_shape(self, cid):
         return self._resolver.node(cid).shape if not isinstance(self._resolver.node(cid), Chunk) else self._resolver.node(cid).shape()
@@ -518,14 +523,14 @@ class Variable:  # py-dcdf __init__.py:246-336 over dataset.rs:642-986
 
 class Dataset:  # py-dcdf __init__.py:52-148 over dataset.rs:60-384
     def __init__(self, inner=None, private=None):
-        if private is not _PRIVATE:
-            raise RuntimeError("Create new Datasets using the 'new' class method.")
+        if private is not _FACTORY_KEY:
+            raise RuntimeError("Dataset objects come from Dataset.new(...) or Resolver.get_dataset(...)")
         (self._coordinates, self._shape, self._variables, self.prev, self.cid, self._resolver) = inner
 
     @classmethod
     def new(cls, coordinates, shape, resolver):
         t, y, x = coordinates
-        return cls(([t, y, x], tuple(int(s) for s in shape), [], None, None, resolver), _PRIVATE)
+        return cls(([t, y, x], tuple(int(s) for s in shape), [], None, None, resolver), _FACTORY_KEY)
 
     @property
     def coordinates(self):
@@ -541,20 +546,20 @@ class Dataset:  # py-dcdf __init__.py:52-148 over dataset.rs:60-384
 
     def _next(self, variables):
         prev = self.cid if self.cid is not None else self.prev  # dataset.rs:144-148
-        return Dataset((self._coordinates, self._shape, variables, prev, None, self._resolver), _PRIVATE)
+        return Dataset((self._coordinates, self._shape, variables, prev, None, self._resolver), _FACTORY_KEY)
 
     def add_variable(self, name, span_size, chunk_size, k2_levels, round=False, fractional_bits=0, dtype=np.float32):
-        encoding = MMEncoding.from_dtype[dtype]
+        encoding = MMEncoding.from_dtype[np.dtype(dtype).type]
         span = _Span(encoding, [0, self._shape[0], self._shape[1]], chunk_size, [])  # an empty span (dataset.rs:128-129)
         cid = self._resolver.save(span.serialize())
         var = Variable((name, int(fractional_bits) if round else None, int(span_size), int(chunk_size), [int(x) for x in k2_levels],
-                        encoding, cid, self._resolver), _PRIVATE)
+                        encoding, cid, self._resolver), _FACTORY_KEY)
         return self._next(self._variables + [var])
 
     def append(self, name, data):
         data = np.asarray(data)
         if data.dtype not in (np.int32, np.int64, np.float32, np.float64):
-            raise ValueError(f"Unsupported dtype: {data.dtype}")
+            raise ValueError("append() takes int32, int64, float32 or float64 arrays, not %s" % data.dtype)
         var = self.get_variable(name)
         if var is None:
             raise KeyError(name)
@@ -582,7 +587,7 @@ class Dataset:  # py-dcdf __init__.py:52-148 over dataset.rs:60-384
                      [(v.name, v._round, v.span_size, v.chunk_size, v._k2_levels, v.encoding, v.cid.hex()) for v in self._variables],
                      self.prev.hex() if self.prev else None)).encode()
         cid = _cid(desc)
-        self._resolver._datasets[cid] = Dataset((self._coordinates, self._shape, self._variables, self.prev, cid, self._resolver), _PRIVATE)
+        self._resolver._datasets[cid] = Dataset((self._coordinates, self._shape, self._variables, self.prev, cid, self._resolver), _FACTORY_KEY)
         self.cid = cid
         return cid
 
@@ -603,18 +608,19 @@ class Dataset:  # py-dcdf __init__.py:52-148 over dataset.rs:60-384
         raise AttributeError(name)
 
 
-class _Slice:  # py-dcdf __init__.py:339-350
-    def __init__(self, realize):
-        self.realize = realize
+class _Lazy:
+    """What indexing a Variable returns: nothing is decoded until `.data` (or an index into it) is asked for, then once."""
 
-    @functools.cached_property
+    def __init__(self, decode):
+        self._decode = decode
+        self._value = None
+        self._done = False
+
+    @property
     def data(self):
-        return self.realize()
+        if not self._done:
+            self._value, self._done, self._decode = self._decode(), True, None
+        return self._value
 
-
-def _is_int(x):
-    return isinstance(x, (int, np.integer))
-
-
-def _as_slice(x):
-    return slice(x, x + 1) if _is_int(x) else x
+    def __getitem__(self, key):
+        return self.data[key]
