@@ -54,7 +54,7 @@ SYMBOLS = [
     "dcdf_encoder_result", "dcdf_encoder_fetch", "dcdf_encoder_gather_size", "dcdf_encoder_gather", "dcdf_encoder_total_bytes", "dcdf_encoder_destroy", "dcdf_superchunk_build", "dcdf_free_superchunk", "dcdf_chunk_open",
     "dcdf_chunk_close", "dcdf_chunk_info", "dcdf_chunk_get", "dcdf_chunk_fill_cell", "dcdf_chunk_fill_window",
     "dcdf_chunk_search", "dcdf_query_fill_window_batch", "dcdf_query_search_batch", "dcdf_query_fill_window_batch_typed", "dcdf_query_search_batch_mem", "dcdf_query_get_batch", "dcdf_query_fill_cell_batch", "dcdf_chunk_open_batch", "dcdf_chunk_instant_layout", "dcdf_raster_create", "dcdf_raster_destroy", "dcdf_raster_fill_window_batch", "dcdf_raster_search_batch", "dcdf_suggest_fraction", "dcdf_encoder_object_sha256",
-    "dcdf_synth_fill", "dcdf_calib_read", "dcdf_device_alloc", "dcdf_device_free", "dcdf_device_copy", "dcdf_strerror", "dcdf_device_name", "dcdf_abi_version", "dcdf_last_hip_error",
+    "dcdf_synth_fill", "dcdf_calib_read", "dcdf_device_alloc", "dcdf_device_free", "dcdf_device_copy", "dcdf_strerror", "dcdf_device_name", "dcdf_abi_version", "dcdf_last_hip_error", "dcdf_device_pool_trim",
 ]
 
 

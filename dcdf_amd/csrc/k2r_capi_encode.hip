@@ -1021,6 +1021,17 @@ int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint6
         failed = failed || bad;
         return true;
     };
+    // Every early exit leaves the ring as the next caller expects it: no copy still landing in a pinned buffer, no busy mark.
+    auto quiesce = [&](int rc) -> int {
+        (void)hipStreamSynchronize(ring.stream);
+        ring.busy[0] = ring.busy[1] = false;
+        return rc;
+    };
+#define K2R_HIP_Q(call)                                                  \
+    do {                                                                 \
+        hipError_t _e = (call);                                          \
+        if (_e != hipSuccess) return quiesce(k2r::map_hip_error(_e));    \
+    } while (0)
     while (i < n) {
         if (lens[i] == 0) {
             i++;
@@ -1028,28 +1039,29 @@ int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint6
         }
         if (lens[i] > kPinBytes) {  // oversize result: plain copy
             uint8_t* d = dst(i, lens[i]);
-            if (!d) return DCDF_ERR_NOMEM;
-            K2R_HIP(hipMemcpy(d, e->args[i].out, lens[i], hipMemcpyDeviceToHost));
+            if (!d) return quiesce(DCDF_ERR_NOMEM);
+            K2R_HIP_Q(hipMemcpy(d, e->args[i].out, lens[i], hipMemcpyDeviceToHost));
             i++;
             continue;
         }
         const int b = fill & 1;
-        if (!drain(b)) return DCDF_ERR_NO_DEVICE;
+        if (!drain(b)) return quiesce(DCDF_ERR_NO_DEVICE);
         uint64_t used = 0;
         while (i < n && (lens[i] == 0 || (lens[i] <= kPinBytes && used + lens[i] <= kPinBytes))) {
             if (lens[i]) {
-                K2R_HIP(hipMemcpyAsync((uint8_t*)ring.buf[b] + used, e->args[i].out, lens[i], hipMemcpyDeviceToHost, ring.stream));
+                K2R_HIP_Q(hipMemcpyAsync((uint8_t*)ring.buf[b] + used, e->args[i].out, lens[i], hipMemcpyDeviceToHost, ring.stream));
                 pend[b].push_back(i);
                 pend_off[b].push_back(used);
                 used += (lens[i] + 63) & ~63ull;
             }
             i++;
         }
-        K2R_HIP(hipEventRecord(ring.ev[b], ring.stream));
+        K2R_HIP_Q(hipEventRecord(ring.ev[b], ring.stream));
         ring.busy[b] = true;
         fill++;
     }
-    if (!drain(0) || !drain(1)) return DCDF_ERR_NO_DEVICE;
+#undef K2R_HIP_Q
+    if (!drain(0) || !drain(1)) return quiesce(DCDF_ERR_NO_DEVICE);
     return failed ? DCDF_ERR_NOMEM : DCDF_OK;
 }
 }  // namespace k2r
@@ -1110,4 +1122,11 @@ extern "C" const char* dcdf_device_name(void) {
     return rt.ok ? rt.name.c_str() : nullptr;
 }
 extern "C" int dcdf_abi_version(void) { return 3; }
+extern "C" int dcdf_device_pool_trim(uint64_t* freed_bytes) {
+    if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
+    (void)hipDeviceSynchronize();
+    const size_t f = k2r::DevPool::get().drain();
+    if (freed_bytes) *freed_bytes = (uint64_t)f;
+    return DCDF_OK;
+}
 extern "C" int dcdf_last_hip_error(void) { return k2r::last_hip_error(); }

@@ -320,16 +320,17 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
     }
 }
 
-// The compact copy of a block's snapshot instant (see encode_chunk): 16 cells of sub-block j of thread tid, uint16
-// offsets from `base`: words [(j * NT + tid) * 8, +8) (a wave reads 2 KB contiguous per sub-block).
+// The compact copy of a block's snapshot instant (see encode_chunk): the 16 cells of sub-block j of thread tid as uint16
+// offsets from `base`, 8 words at [(j * NT + tid) * 8, +8) (a wave reads 2 KB contiguous per sub-block).  Word 4 * p + c holds
+// cell c of quad 2p (low half) and cell c of quad 2p + 1 (high half): the extremes of two quads then cost three packed
+// 16-bit min / max each, and a difference against an int32 cell reads its half through an operand selector.
 template <class C>
 K2R_HD uint32_t compact_slot(int tid, int j) {
     return (uint32_t)j * (uint32_t)C::NT + (uint32_t)tid;
 }
 template <class C>
-K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int32_t (&dst)[16]) {
+K2R_HD void load_compact_raw(const uint32_t* scmp, int tid, int j, uint32_t (&w)[8]) {
     const uint32_t* p = scmp + (size_t)compact_slot<C>(tid, j) * 8;
-    uint32_t w[8];
 #if defined(__HIP_DEVICE_COMPILE__)
     // wave-uniform base (SGPR pair) + 32-bit byte offset per thread: no 64-bit address arithmetic on the VALU
     typedef __attribute__((address_space(1))) const char* gptr;
@@ -342,23 +343,77 @@ K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int
 #else
     for (int i = 0; i < 8; i++) w[i] = p[i];
 #endif
+}
+template <class C>
+K2R_HD void load_compact(const uint32_t* scmp, int tid, int j, int32_t base, int32_t (&dst)[16]) {
+    uint32_t w[8];
+    load_compact_raw<C>(scmp, tid, j, w);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        dst[2 * i] = base + (int32_t)(w[i] & 0xffffu);
-        dst[2 * i + 1] = base + (int32_t)(w[i] >> 16);
-    }
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            dst[8 * p + c] = base + (int32_t)(w[4 * p + c] & 0xffffu);
+            dst[8 * p + 4 + c] = base + (int32_t)(w[4 * p + c] >> 16);
+        }
 }
 template <class C>
 K2R_HD void store_compact(uint32_t* scmp, int tid, int j, int32_t base, const int32_t (&src)[16]) {
     uint32_t* p = scmp + (size_t)compact_slot<C>(tid, j) * 8;
     uint32_t w[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) w[i] = (uint32_t)(src[2 * i] - base) | ((uint32_t)(src[2 * i + 1] - base) << 16);
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) w[4 * q + c] = (uint32_t)(src[8 * q + c] - base) | ((uint32_t)(src[8 * q + 4 + c] - base) << 16);
 #if defined(__HIP_DEVICE_COMPILE__)
     *(__attribute__((address_space(1))) uint4*)p = uint4{w[0], w[1], w[2], w[3]};
     *(__attribute__((address_space(1))) uint4*)(p + 4) = uint4{w[4], w[5], w[6], w[7]};
 #else
     for (int i = 0; i < 8; i++) p[i] = w[i];
+#endif
+}
+// two uint16 lanes per word
+K2R_HD uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+#else
+    const uint32_t lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+    return lo | (hi << 16);
+#endif
+}
+K2R_HD uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+#else
+    const uint32_t lo = (a & 0xffffu) > (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+    return lo | (hi << 16);
+#endif
+}
+// v != 0 as 0 / 1 without a compare (the optimizer turns min(v, 1) back into compare + select, hence the asm)
+K2R_HD uint32_t nz(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
+    return v != 0 ? 1u : 0u;
+#endif
+}
+// a * b for operands below 2^24 (a full-rate multiply; the 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+K2R_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
+// (lo & 0xffff) | (hi << 16)
+K2R_HD uint32_t pk_lo16(uint32_t lo, uint32_t hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+#else
+    return (lo & 0xffffu) | (hi << 16);
 #endif
 }
 
@@ -550,9 +605,9 @@ struct EncPool {
     static constexpr int POOL_BMV1 = 12 * C::NBLK;              // word offset of bmV1 (WV+1 words)
     static constexpr int POOL_PREFV = POOL_BMV1 + C::WV + 1;    // word offset of prefV (WV+2 words)
 #ifdef K2R_PROFILE
-    static constexpr int POOLFILL = 4900 - 16 * NPROF * 4;  // (the per-wave cycle sums of the diagnostic build live in LDS too)
+    static constexpr int POOLFILL = 1828 - 16 * NPROF * 4;  // (the per-wave cycle sums of the diagnostic build live in LDS too)
 #else
-    static constexpr int POOLFILL = 4900;
+    static constexpr int POOLFILL = 1828;
 #endif
     static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? POOLFILL : 0);  // sidelen 256: LDS filled to 160 KB
     // The stash's two record kinds have fixed shares of the pool (I records grow up from word 0, Q records down from POOLW);
@@ -589,6 +644,12 @@ struct EncShared : EncPool<C> {
     // per-thread exclusive prefixes for stash emission (records find their owner's): [0] I1 | I2 << 16 of the winner,
     // [1] second bytes of cell values, [2] second bytes of height-1 values: Lmax | Lmin << 16
     uint32_t pfx[3][C::NBLK];
+    // Which values of a block's stash records need a second byte, left by the pre-pass over the records (sparse work) so that
+    // the dense phase 1 does no per-value byte bookkeeping: lq = 4 bits per Q record of the block, in ordinal order (<= 16
+    // records); li = 8 bits per I record (<= 4): Lmax flags of its four quads | Lmin flags of the internal ones << 4.  The
+    // owner's counts (phase 3) and a record's "second bytes before me" (emission) are popcounts over these words.
+    uint32_t lq[C::NBLK][2];
+    uint32_t li[C::NBLK];
     uint32_t tbS[C::TBW], tbL[C::TBW];  // "internal" flags of the nodes at heights 4..H, bit = top_off(h) - NBLK + j
     uint32_t tbP[C::TBW + 1];           // per-word exclusive popcount prefix of the winner's flags
     uint32_t ttR[C::H + 2];             // rank (over those flags) of the first node of height h
@@ -618,15 +679,18 @@ K2R_HD bool guard_ok(EX& ex, bool ok, uint32_t code, uint32_t inst, uint32_t tid
 }
 // position guard: returns pos when pos + span <= limit, else 0 (a safe in-range position: the tile is reported as
 // failed and its output discarded) -- no branch, no divergence
-template <class EX>
+// UNIFORM_SPAN = false where `span` differs from lane to lane (the eqB runs of 0..4 bits): the bound is then a vector operand
+// (an "s" constraint would only be right as long as the compiler happened to keep the per-lane value in a VGPR anyway)
+template <bool UNIFORM_SPAN = true, class EX>
 K2R_HD uint32_t guard_pos(EX& ex, uint32_t pos, uint32_t span, uint32_t limit, uint32_t code) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(K2R_GUARD_FULL)
     // Release build of the GPU kernel: the position is clamped into [0, limit - span] with ONE instruction (median of
-    // pos, 0 and the wave-uniform bound), which is all the memory safety needs; the recording form below cost five
+    // pos, 0 and the bound), which is all the memory safety needs; the recording form below cost five
     // per site (~7 % of the kernel's instructions).  A logic error then shows up as wrong bytes (parity tests) instead
     // of ST_INTERNAL; the recording form still runs in the simulator suite and in -DK2R_GUARD_FULL builds.
     int32_t r;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"((int32_t)pos), "s"((int32_t)limit - (int32_t)span));
+    if (UNIFORM_SPAN) asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"((int32_t)pos), "s"((int32_t)limit - (int32_t)span));
+    else asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"((int32_t)pos), "v"((int32_t)limit - (int32_t)span));
     (void)ex; (void)code;
     return (uint32_t)r;
 #else
@@ -1079,19 +1143,204 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         // ================= phase 1: stream the tile in 4x4 sub-blocks; thread-local counts ==============
         // Nothing but four per-height-2 summaries survives this phase in registers: cells are re-read on
         // demand at emission, and only under visited subtrees (sparse for logs).
-        ex.par([&](int tid, EncRegs& r) {
+        //
+        // Two forms.  The LEAN one runs whenever the instant is compared with a compact snapshot copy on an unpadded tile
+        // (every log of the benchmark): straight-line code on the copy's packed 16-bit cells -- differences, extremes and
+        // node values are all taken relative to the copy's base (the constant is removed from the few values that are
+        // emitted, EncShared::lq / rec_corr) -- with ONE stash allocation per wave and sub-block (ex.stash_alloc) instead
+        // of one LDS atomic per record inside a divergent branch.  The general form covers the first instant of a block
+        // (no snapshot to compare with), snapshots beyond 16 bits of range and padded tiles.
+#ifndef K2R_NO_LEAN
+        const bool lean = !PADDED && have_s && s_cmp;
+#else
+        const bool lean = false;
+#endif
+        if (lean) ex.par([&](int tid, EncRegs& r) {
+            uint32_t r0, c0;
+            blk_origin(tid, r0, c0);
+            const uint32_t ltid = opaque((uint32_t)tid);  // (anything derived from the thread index must not be hoisted: see opaque)
+            int32_t err = 0;
+            sh.lq[ltid][0] = 0;
+            sh.lq[ltid][1] = 0;
+            sh.li[ltid] = 0;
+            uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0, eqbits = 0, cntbits = 0, u2 = 0, Z = 0;
+            int32_t mn3 = 0, mx3 = 0, dref = 0;
+            uint32_t smn3 = 0, smx3 = 0;  // the snapshot's extremes as offsets from s_base, like the copy's cells
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                sched_fence();
+                int32_t t[16];
+                uint32_t w[8];
+                load_sub16<false, VEC>(ta, inst, r0, c0, j, t, err);
+                load_compact_raw<C>(cmp, (int)ltid, j, w);
+                // extremes of the instant's quads and of the node (snapshot.rs:476-497)
+                int32_t mn1[4], mx1[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    mn1[q] = min4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                    mx1[q] = max4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                }
+                const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]), mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
+                // the same for the snapshot, two quads per packed operation: sn[p] = minima of quads 2p | 2p + 1 << 16
+                uint32_t sn[2], sx[2];
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    sn[p] = pk_min_u16(pk_min_u16(w[4 * p], w[4 * p + 1]), pk_min_u16(w[4 * p + 2], w[4 * p + 3]));
+                    sx[p] = pk_max_u16(pk_max_u16(w[4 * p], w[4 * p + 1]), pk_max_u16(w[4 * p + 2], w[4 * p + 3]));
+                }
+                const uint32_t sn2p = pk_min_u16(sn[0], sn[1]), sx2p = pk_max_u16(sx[0], sx[1]);
+                // (opaque: the reductions happen here, not at the end of the block with their inputs spilled in between)
+                const uint32_t smn2 = opaque((sn2p & 0xffffu) < (sn2p >> 16) ? (sn2p & 0xffffu) : (sn2p >> 16));
+                const uint32_t smx2 = opaque((sx2p & 0xffffu) > (sx2p >> 16) ? (sx2p & 0xffffu) : (sx2p >> 16));
+                sched_fence();
+                // cell differences against the copy (all of them s_base too large: equality tests do not care)
+                int32_t d[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t ww = w[4 * (q >> 1) + c];
+                        d[4 * q + c] = t[4 * q + c] - (int32_t)((q & 1) ? (ww >> 16) : (ww & 0xffffu));
+                    }
+                // per quad: "all four differences equal" <=> x == 0 (log.rs:780,805); internal <=> not uniform and not equal.
+                // Flags are 0 / 1 integers made without compares (nz): no mask registers, nothing for the compiler to re-derive.
+                uint32_t x[4], recw[4], pq[4], tb1 = 0, e4 = 0, su = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    x[q] = (uint32_t)((d[4 * q] ^ d[4 * q + 1]) | (d[4 * q] ^ d[4 * q + 2]) | (d[4 * q] ^ d[4 * q + 3]));
+                    const uint32_t u1 = nz((uint32_t)(mn1[q] ^ mx1[q]));
+                    pq[q] = u1 & nz(x[q]);               // log.rs:137-152
+                    tb1 = (tb1 << 1) | pq[q];
+                    e4 = (e4 << 1) | (u1 ^ pq[q]);      // T = 0 and not uniform: "equal" (log.rs:137-144)
+                    su += u1;
+                    const uint32_t sxq = (q & 1) ? (sx[q >> 1] >> 16) : (sx[q >> 1] & 0xffffu);
+                    const uint32_t snq = (q & 1) ? (sn[q >> 1] >> 16) : (sn[q >> 1] & 0xffffu);
+                    recw[q] = pk_lo16((uint32_t)(mx1[q] - (int32_t)sxq), (uint32_t)(mn1[q] - (int32_t)snq));  // log.rs:133,148 (+ s_base)
+                }
+                const uint32_t X = x[0] | x[1] | x[2] | x[3] | (uint32_t)((d[0] ^ d[4]) | (d[0] ^ d[8]) | (d[0] ^ d[12]));
+                const uint32_t ne2 = nz(X), nu2 = nz((uint32_t)(mn2 ^ mx2)), p2 = ne2 & nu2;  // P2L
+                if (j == 0) dref = d[0];
+                // (through nz: left as one OR-sum the optimizer rewrites "== 0" of it into a conjunction of compares over every
+                // term, all of them kept alive -- spilled -- until the end of the block)
+                Z |= ne2 | nz((uint32_t)(d[0] ^ dref));
+                sched_fence();
+                // stash: the wave's records of this sub-block in one allocation
+                const uint32_t nq = popc32(tb1);
+                uint32_t slotQ, slotI, endQ, endI;
+                ex.stash_alloc(nq | (p2 << 16), &sh.stQ, &sh.stI, slotQ, slotI, endQ, endI);
+                uint32_t ord = lI1;
+                // Q record: owner, ordinal among the owner's internal quads, the four cell differences;
+                // I record: owner, ordinals, T bits, eqB bits and the Lmax|Lmin pairs of the four quads
+                const uint32_t p0 = ltid | (lI2 << 10) | (lI1 << 12) | (tb1 << 16) | (e4 << 20);
+                if (endQ <= (uint32_t)SH::CAPQ_REC && endI <= (uint32_t)SH::CAPI_REC) {  // (wave-uniform) nothing of this wave overflows
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t q0 = ltid | (ord << 10);
+                        const uint32_t q1 = pk_lo16((uint32_t)d[4 * q], (uint32_t)d[4 * q + 1]), q2 = pk_lo16((uint32_t)d[4 * q + 2], (uint32_t)d[4 * q + 3]);
+                        uint32_t* o = sh.pool + ((uint32_t)SH::POOLW - 3u - mul24(slotQ, 3u));
+                        if (pq[q]) {
+                            o[0] = q0;
+                            o[1] = q1;
+                            o[2] = q2;
+                        }
+                        slotQ += pq[q];
+                        ord += pq[q];
+                    }
+                    if (p2) {
+                        uint32_t* o = sh.pool + mul24(slotI, 5u);
+                        o[0] = p0;
+                        o[1] = recw[0];
+                        o[2] = recw[1];
+                        o[3] = recw[2];
+                        o[4] = recw[3];
+                    }
+                } else {  // (separate code paths on purpose: an LDS-or-global pointer would turn both into FLAT stores)
+#pragma unroll 1
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t q0 = ltid | (ord << 10);
+                        const uint32_t dd[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
+                        const uint32_t q1 = pk_lo16(dd[0], dd[1]), q2 = pk_lo16(dd[2], dd[3]);
+                        if (pq[0]) {
+                            if (slotQ < (uint32_t)SH::CAPQ_REC) {
+                                uint32_t* o = sh.pool + (SH::POOLW - 3u * (slotQ + 1u));
+                                o[0] = q0;
+                                o[1] = q1;
+                                o[2] = q2;
+                            } else {
+                                gstore_words3(ovQ + 3u * (slotQ - (uint32_t)SH::CAPQ_REC), q0, q1, q2);
+                            }
+                        }
+                        slotQ += pq[0];
+                        ord += pq[0];
+                        // next quad into place (a rolled loop: this path is cold, its code should be small)
+                        pq[0] = pq[1]; pq[1] = pq[2]; pq[2] = pq[3];
+#pragma unroll
+                        for (int i = 0; i < 12; i++) d[i] = d[i + 4];
+                    }
+                    if (p2) {
+                        if (slotI < (uint32_t)SH::CAPI_REC) {
+                            uint32_t* o = sh.pool + 5u * slotI;
+                            o[0] = p0;
+                            o[1] = recw[0];
+                            o[2] = recw[1];
+                            o[3] = recw[2];
+                            o[4] = recw[3];
+                        } else {
+                            gstore_words5(ovI + 5u * (slotI - (uint32_t)SH::CAPI_REC), p0, recw[0], recw[1], recw[2], recw[3]);
+                        }
+                    }
+                }
+                sched_fence();
+                const bool un2 = nu2 == 0, eq2 = ne2 == 0;
+                const uint32_t P2Lc = p2;
+                sI1 += su;
+                sI2 += nu2;
+                cntbits |= (su << (4 + 3 * j)) | (nq << (16 + 3 * j));
+                lI1 += nq;
+                lI2 += P2Lc;
+                u2 |= (un2 ? 1u : 0u) << j;
+                eqbits |= (eq2 ? 1u : 0u) << j;
+                r.d2[j] = pk_lo16((uint32_t)(mx2 - (int32_t)smx2), (uint32_t)(mn2 - (int32_t)smn2));  // log.rs:133,148 (+ s_base)
+                mn3 = j == 0 ? mn2 : (mn2 < mn3 ? mn2 : mn3);
+                mx3 = j == 0 ? mx2 : (mx2 > mx3 ? mx2 : mx3);
+                smn3 = j == 0 ? smn2 : (smn2 < smn3 ? smn2 : smn3);
+                smx3 = j == 0 ? smx2 : (smx2 > smx3 ? smx2 : smx3);
+            }
+            // raw int32 rows are not range-checked cell by cell: the block's extremes decide (value-range contract)
+            if (VEC == 1 && (mn3 < -VALUE_LIMIT || mx3 >= VALUE_LIMIT) && err == 0) err = ERR_RANGE;
+            sh.tmin[tid] = mn3;
+            sh.tmax[tid] = mx3;
+            r.sc[0] = sI1 | (sI2 << 16);
+            const int32_t smn3t = s_base + (int32_t)smn3, smx3t = s_base + (int32_t)smx3;
+            // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: below 2^15 in magnitude none of them needs a
+            // third byte (and the 16 bits kept of each are all of it); otherwise the exact classes_pass is requested
+            const uint32_t wide = (mn3 - smx3t < -32768 || mx3 - smn3t > 32767) ? 1u : 0u;
+            sh.smin[tid] = smn3t;
+            sh.smax[tid] = smx3t;
+            sh.diff[tid] = dref - s_base;
+            sh.eq[tid] = Z == 0 ? 1u : 0u;
+            r.flags = eqbits | cntbits | (wide << 28);
+            r.u2 = u2;
+            if (tid < C::TBW) {
+                sh.tbS[tid] = 0;
+                sh.tbL[tid] = 0;
+            }
+            r.sc[3] = lI1 | (lI2 << 16);
+            if (err != 0) ex.lds_min(&sh.err, err);
+        });
+        else ex.par([&](int tid, EncRegs& r) {
             uint32_t r0, c0;
             blk_origin(tid, r0, c0);
             int32_t err = 0;
             const bool inv3 = inval(r0, c0);
             uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0;
-            // Log values of this block needing a second byte, per level, packed in one register (the phase is register-
-            // bound): cL0 @0 (7b) cells, cL1 @7 (5b) / cL2 via pend2 @12 (3b) height-1 / height-2 Lmax values, mL1 @15 (5b) /
-            // mL2 @20 (3b) height-1 / height-2 Lmin values, pend1 @23 (3b).  pend* are counted before it is known whether
-            // their parent is internal.  The running values double as the place of a stash record's second bytes among
-            // its owner's (EM_ONE emission).
-            uint32_t lc = 0, cL2 = 0;
-            auto lng = [](int32_t v) -> uint32_t { return ((uint32_t)v + 128u) > 255u ? 1u : 0u; };  // zig-zag(v) > 0xff
+            // (which log values need a second byte is not this phase's business: the pre-pass over the stash records
+            // works that out for the few values that are actually emitted, see EncShared::lq)
+            if (have_s) {
+                sh.lq[tid][0] = 0;
+                sh.lq[tid][1] = 0;
+                sh.li[tid] = 0;
+            }
             int32_t df2_0 = 0, mn3 = 0, mx3 = 0, smn3 = 0, smx3 = 0;
             uint32_t eqbits = 0, eqall = 1, cntbits = 0, wide = 0, u2 = 0;
 #pragma unroll
@@ -1127,8 +1376,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     else load_sub16<PADDED, VEC>(ta, s_idx, r0, c0, j, s16, err);
                     int32_t smn1[4], smx1[4], df1[4];
                     bool eq1[4];
-                    uint32_t recw[4], tb1 = 0, erun = 0;  // the I record of this node (see EncShared::pool)
-                    const uint32_t pre1 = lI1, lc0 = lc;
+                    uint32_t recw[4], tb1 = 0, e4 = 0;  // the I record of this node (see EncShared::pool)
+                    const uint32_t pre1 = lI1;
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         const uint32_t rq = rj + 2 * (qq >> 1), cq = cj + 2 * (qq & 1);
@@ -1147,12 +1396,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         const int32_t vn1 = mn1[qq] - smn1[qq];                          // log.rs:148
                         recw[qq] = ((uint32_t)vx1 & 0xffffu) | ((uint32_t)vn1 << 16);
                         tb1 = (tb1 << 1) | (P1L ? 1u : 0u);
-                        if (!P1L) {  // T = 0: one eqB bit, set iff "equal" rather than uniform (log.rs:137-144)
-                            erun = (erun << 1) | ((inv1[qq] || mn1[qq] == mx1[qq]) ? 0u : 1u);
-                        }
+                        // a T = 0 quad has one eqB bit, set iff "equal" rather than uniform (log.rs:137-144); kept per quad here
+                        // (bit 3 - qq), packed to a run of the T = 0 quads when the record is emitted
+                        e4 = (e4 << 1) | ((!P1L && !(inv1[qq] || mn1[qq] == mx1[qq])) ? 1u : 0u);
                         if (P1L) {  // Q record: owner, ordinal among the owner's internal quads, the four cell diffs
                             const uint32_t m = ex.lds_add(&sh.stQ, 1u);
-                            const uint32_t q0 = (uint32_t)tid | (lI1 << 10) | ((lc & 127u) << 14);
+                            const uint32_t q0 = (uint32_t)tid | (lI1 << 10);
                             const uint32_t q1 = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16);
                             const uint32_t q2 = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
                             if (m < (uint32_t)SH::CAPQ_REC) {
@@ -1166,8 +1415,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         }
                         lI1 += P1L ? 1u : 0u;
                         cntbits += (P1L ? 1u : 0u) << (16 + 3 * j);  // bits 16..27: internal quads per j, log
-                        lc += P1L ? lng(d[0]) + lng(d[1]) + lng(d[2]) + lng(d[3]) + (lng(vn1) << 15) : 0u;  // cells: t - s; Lmin
-                        lc += lng(vx1) << 23;
                     }
                     const int32_t smn2 = min4(smn1[0], smn1[1], smn1[2], smn1[3]);
                     const int32_t smx2 = max4(smx1[0], smx1[1], smx1[2], smx1[3]);
@@ -1178,8 +1425,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const bool P2L = !inv2 && mn2 != mx2 && !eq2;
                     if (P2L) {  // I record: owner, ordinals, T / eqB runs and the Lmax|Lmin pairs of the four quads
                         const uint32_t k = ex.lds_add(&sh.stI, 1u);
-                        const uint32_t p0 = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (tb1 << 16) | (erun << 20) | (((lc >> 7) & 31u) << 24) |
-                                            (((lc0 >> 15) & 31u) << 28);
+                        const uint32_t p0 = (uint32_t)tid | (lI2 << 10) | (pre1 << 12) | (tb1 << 16) | (e4 << 20);
                         if (k < (uint32_t)SH::CAPI_REC) {
                             uint32_t* p = sh.pool + 5u * k;
                             p[0] = p0;
@@ -1192,8 +1438,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                         }
                     }
                     lI2 += P2L ? 1u : 0u;
-                    lc += P2L ? (((lc >> 23) & 7u) << 7) + (lng(mn2 - smn2) << 20) : 0u;
-                    lc = (lc & 0x7fffffu) + (lng(inv2 ? 0 : mx2 - smx2) << 12);  // pend1 starts over
                     smn3 = j == 0 ? smn2 : (smn2 < smn3 ? smn2 : smn3);
                     smx3 = j == 0 ? smx2 : (smx2 > smx3 ? smx2 : smx3);
                     r.d2[j] = ((uint32_t)(inv2 ? 0 : mx2 - smx2) & 0xffffu) | ((uint32_t)(mn2 - smn2) << 16);  // log.rs:133,148
@@ -1212,8 +1456,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             (void)P3S;
             if (have_s) {
                 const bool eq3 = eqall != 0;
-                const bool PL3 = !inv3 && mn3 != mx3 && !eq3;
-                cL2 = PL3 ? (lc >> 12) & 7u : 0u;
                 // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: below 2^15 in magnitude none of them
                 // needs a third byte; otherwise the exact classes_pass is requested (bit 60 of the top pack)
                 const int32_t lo_b = mn3 - smx3, hi_b = mx3 - smn3;
@@ -1230,9 +1472,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 sh.tbL[tid] = 0;
             }
             r.sc[3] = lI1 | (lI2 << 16);
-            r.sc[7] = lc & 127u;
-            r.sc[8] = ((lc >> 7) & 31u) | (cL2 << 16);
-            r.sc[9] = ((lc >> 15) & 31u) | (((lc >> 20) & 7u) << 16);
             if (err != 0) ex.lds_min(&sh.err, err);
         });
         const int32_t perr = ex.uni(sh.err);
@@ -1242,6 +1481,52 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             break;
         }
         ex.stamp(0);  // phase 1: load + thread-local analysis
+
+        // ================= pre-pass over the stash records: which of their values need a second byte ==========
+        // Sparse work (about an eighth of the quads and two fifths of the height-2 nodes of a benchmark log have a record),
+        // taken out of the dense phase 1.  Records are in arrival order; each ORs its flags into its owner's words at the
+        // place its ordinal gives.  rec_corr: what phase 1 left added to every 16-bit value of a record (see lean phase 1).
+        const bool rec_ovf = stI > (uint32_t)SH::CAPI_REC || stQ > (uint32_t)SH::CAPQ_REC;
+        const uint32_t rec_corr = lean ? (uint32_t)s_base & 0xffffu : 0u;
+        auto rec16 = [&](uint32_t half) -> int32_t { return (int32_t)(int16_t)(uint16_t)(half - rec_corr); };
+        auto lng = [](int32_t v) -> uint32_t { return ((uint32_t)v + 128u) > 255u ? 1u : 0u; };  // zig-zag(v) > 0xff
+        if (have_s) {
+            // records that overflowed to global scratch are read by other threads: their stores must have landed
+            if (rec_ovf) ex.barrier_global();
+            ex.par_nosync([&](int tid, EncRegs&) {
+                for (uint32_t m = (uint32_t)tid; m < stQ; m += NT) {
+                    uint32_t q[3];
+                    if (m < (uint32_t)SH::CAPQ_REC) {
+#pragma unroll
+                        for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::POOLW - 3u * (m + 1u) + i];
+                    } else {
+                        gload_words<3>(ovQ + 3u * (m - (uint32_t)SH::CAPQ_REC), q);
+                    }
+                    const uint32_t own = q[0] & 1023u, ord = (q[0] >> 10) & 15u;
+                    const uint32_t f = lng(rec16(q[1] & 0xffffu)) | (lng(rec16(q[1] >> 16)) << 1) | (lng(rec16(q[2] & 0xffffu)) << 2) |
+                                       (lng(rec16(q[2] >> 16)) << 3);
+                    if (f) ex.lds_or(&sh.lq[own][ord >> 3], f << (4u * (ord & 7u)));
+                }
+                for (uint32_t k = (uint32_t)tid; k < stI; k += NT) {
+                    uint32_t rec[5];
+                    if (k < (uint32_t)SH::CAPI_REC) {
+#pragma unroll
+                        for (int i = 0; i < 5; i++) rec[i] = sh.pool[5u * k + i];
+                    } else {
+                        gload_words<5>(ovI + 5u * (k - (uint32_t)SH::CAPI_REC), rec);
+                    }
+                    const uint32_t own = rec[0] & 1023u, ord2 = (rec[0] >> 10) & 3u, tb1 = (rec[0] >> 16) & 15u;
+                    uint32_t f = 0;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        f |= lng(rec16(rec[1 + qq] & 0xffffu)) << qq;                                   // Lmax of quad qq
+                        f |= (((tb1 >> (3 - qq)) & 1u) & lng(rec16(rec[1 + qq] >> 16))) << (4 + qq);     // Lmin, internal quads only
+                    }
+                    if (f) ex.lds_or(&sh.li[own], f << (8u * ord2));
+                }
+            });
+            if (H < 4) ex.barrier();  // (phase 3 reads the flags; taller trees have phase 2's barriers in between)
+        }
 
         // ================= phase 2: heights 4..H in LDS (snapshot.rs:476-497, log.rs:776-806) ==========
         for (int h = 4; h <= H; h++) {
@@ -1360,6 +1645,27 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             r.sc[4] = lTop;
             r.sc[5] = lMax.c1 | (lMin.c1 << 16);
             r.sc[6] = wide;
+            // second bytes of this block's log values per level: cells and height-1 values from the flags the pre-pass left,
+            // height-2 values from the four pairs phase 1 kept (Lmax of all four when the block's own node is internal, Lmin of
+            // the internal ones); meaningful for narrow logs only, like the pairs themselves
+            uint32_t cL0 = 0, cL1 = 0, mL1 = 0, cL2 = 0, mL2 = 0;
+            if (have_s) {
+                const uint32_t fl = sh.li[tid];
+                cL0 = popc32(sh.lq[tid][0]) + popc32(sh.lq[tid][1]);
+                cL1 = popc32(fl & 0x0f0f0f0fu);
+                mL1 = popc32(fl & 0xf0f0f0f0u);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int32_t vx = rec16(r.d2[j] & 0xffffu), vn = rec16(r.d2[j] >> 16);
+                    r.d2[j] = ((uint32_t)vx & 0xffffu) | ((uint32_t)vn << 16);
+                    const bool P2L = ((r.u2 >> j) & 1u) == 0 && ((r.flags >> j) & 1u) == 0;
+                    cL2 += lI3 ? lng(vx) : 0u;
+                    mL2 += P2L ? lng(vn) : 0u;
+                }
+            }
+            r.sc[7] = cL0;
+            r.sc[8] = cL1 | (cL2 << 16);
+            r.sc[9] = mL1 | (mL2 << 16);
         });
         ex.stamp(2);  // phase 3: own/top nodes
         // one scan serves both the totals the planner needs and the prefixes emission needs (of both candidates:
@@ -1688,8 +1994,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             }
         });
 
-        // records that overflowed to global scratch are read by other threads: their stores must have landed
-        if (use_stash && (stI > (uint32_t)SH::CAPI_REC || stQ > (uint32_t)SH::CAPQ_REC)) ex.barrier_global();
+        // (records that overflowed to global scratch: the pre-pass already waited for their stores to land)
         ex.stamp(4);  // sizes, heuristic, clears, header
         const uint32_t nlevV = ex.uni(DV.nlev), nlevM = ex.uni(DM.nlev);
         const DacSink sinkV{io + ex.uni(DV.by_off[0]), sh.bmV0, listV, &sh.nlistV, ex.uni(DV.n[0]), ex.uni(DV.n[1]), inst, kGuardVPos,
@@ -1812,7 +2117,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 }
                 emit4<0, GMODE>(ex, sinkV, p2, z2v[0], z2v[1], z2v[2], z2v[3], tid, sh.pl.lngV[2] + (r.pf_l2 & 0xffffu));
                 bm_or_run(ex, sh.bmT, guard_pos(ex, p2, 4, TT.LT, kGuardTRun2), 4, tb2);
-                if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
+                if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos<false>(ex, TT.offZ[2] + 4 * E3 - E2, elen, TT.LT - TT.M0, kGuardE2), elen, erun);
                 uint32_t n2 = 0, pre = E1, lm = sh.pl.lngM[2] + (r.pf_l2 >> 16);
                 const uint32_t cshift = as_snapshot ? 4u : 16u;
 #pragma unroll
@@ -1860,21 +2165,30 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const uint32_t pf = sh.pfx[0][own], pl = sh.pfx[2][own];
                     const uint32_t kk = ((pf >> 16) & 0x3fffu) + ((hdr >> 10) & 3u);  // rank among internal height-2 nodes
                     const uint32_t pre = (pf & 0xffffu) + ((hdr >> 12) & 15u);        // internal quads before this node
-                    const uint32_t tb1 = (hdr >> 16) & 15u, erun = (hdr >> 20) & 15u, elen = 4u - popc32(tb1);
+                    const uint32_t tb1 = (hdr >> 16) & 15u, e4 = (hdr >> 20) & 15u, elen = 4u - popc32(tb1);
+                    // the eqB bits of the T = 0 quads, packed to a run (first quad = most significant bit)
+                    uint32_t erun = 0;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const uint32_t t0 = ((tb1 >> (3 - qq)) & 1u) ^ 1u;
+                        erun = (erun << t0) | ((e4 >> (3 - qq)) & t0);
+                    }
+                    // second bytes of this block's height-1 values that come before this record's (EncShared::li)
+                    const uint32_t below = sh.li[own] & ((1u << (8u * ((hdr >> 10) & 3u))) - 1u);
                     uint32_t w[4];
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) w[qq] = rec[1 + qq];
                     const uint32_t p1 = offV1 + 4 * kk;
-                    emit4<0, EM_ONE>(ex, sinkV, p1, zz32((int32_t)(int16_t)(w[0] & 0xffffu)), zz32((int32_t)(int16_t)(w[1] & 0xffffu)),
-                                     zz32((int32_t)(int16_t)(w[2] & 0xffffu)), zz32((int32_t)(int16_t)(w[3] & 0xffffu)), tid,
-                                     lv1 + (pl & 0xffffu) + ((hdr >> 24) & 15u));
+                    emit4<0, EM_ONE>(ex, sinkV, p1, zz32(rec16(w[0] & 0xffffu)), zz32(rec16(w[1] & 0xffffu)),
+                                     zz32(rec16(w[2] & 0xffffu)), zz32(rec16(w[3] & 0xffffu)), tid,
+                                     lv1 + (pl & 0xffffu) + popc32(below & 0x0f0f0f0fu));
                     bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, lt, kGuardTRun1), 4, tb1);
-                    bm_or_run(ex, sh.bmE, guard_pos(ex, offZ1 + 4 * kk - pre, elen, ne, kGuardE1), elen, erun);
-                    uint32_t n1 = 0, lm = lm1 + (pl >> 16) + (hdr >> 28);
+                    bm_or_run(ex, sh.bmE, guard_pos<false>(ex, offZ1 + 4 * kk - pre, elen, ne, kGuardE1), elen, erun);
+                    uint32_t n1 = 0, lm = lm1 + (pl >> 16) + popc32(below & 0xf0f0f0f0u);
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         if ((tb1 >> (3 - qq)) & 1u) {
-                            const uint32_t zm = zz32((int32_t)w[qq] >> 16);
+                            const uint32_t zm = zz32(rec16(w[qq] >> 16));
                             emit_val<1, EM_ONE>(ex, sinkM, offI1 + pre + n1, zm, tid, lm);
                             lm += zm > 0xffu ? 1u : 0u;
                             n1++;
@@ -1884,7 +2198,6 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 guard_flush(ex);
               });
             };
-            const bool rec_ovf = stI > (uint32_t)SH::CAPI_REC || stQ > (uint32_t)SH::CAPQ_REC;
             if (rec_ovf) passI(EmTag<1>{});
             else passI(EmTag<0>{});
             ex.stamp(11);
@@ -1903,10 +2216,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                     const uint32_t hdr = q[0], a = q[1], b = q[2];
                     const uint32_t own = hdr & 1023u;
-                    const uint32_t pos = (sh.pfx[0][own] & 0xffffu) + ((hdr >> 10) & 15u);  // rank among internal quads
-                    emit4<0, EM_ONE>(ex, sinkV, offV0 + 4 * pos, zz32((int32_t)(int16_t)(a & 0xffffu)), zz32((int32_t)a >> 16),
-                                     zz32((int32_t)(int16_t)(b & 0xffffu)), zz32((int32_t)b >> 16), tid,
-                                     lv0 + sh.pfx[1][own] + ((hdr >> 14) & 63u));
+                    const uint32_t ord = (hdr >> 10) & 15u;
+                    const uint32_t pos = (sh.pfx[0][own] & 0xffffu) + ord;  // rank among internal quads
+                    // second bytes of this block's cell values that come before this record's (EncShared::lq)
+                    const uint32_t f0 = sh.lq[own][0], f1 = sh.lq[own][1], cut = (1u << (4u * (ord & 7u))) - 1u;
+                    const uint32_t before = ord < 8u ? popc32(f0 & cut) : popc32(f0) + popc32(f1 & cut);
+                    emit4<0, EM_ONE>(ex, sinkV, offV0 + 4 * pos, zz32(rec16(a & 0xffffu)), zz32(rec16(a >> 16)),
+                                     zz32(rec16(b & 0xffffu)), zz32(rec16(b >> 16)), tid, lv0 + sh.pfx[1][own] + before);
                 }
                 guard_flush(ex);
               });
@@ -2013,7 +2329,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     const uint32_t p1 = TT.offV[1] + 4 * k;  // level order: four children per internal parent
                     emit4<0>(ex, sinkV, p1, z1v[0], z1v[1], z1v[2], z1v[3], tid);
                     bm_or_run(ex, sh.bmT, guard_pos(ex, p1, 4, TT.LT, kGuardTRun1), 4, tb1);
-                    if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos(ex, TT.offZ[1] + 4 * k - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
+                    if (!as_snapshot) bm_or_run(ex, sh.bmE, guard_pos<false>(ex, TT.offZ[1] + 4 * k - pre, elen, TT.LT - TT.M0, kGuardE1), elen, erun);
                     uint32_t n1 = 0;
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {

@@ -253,6 +253,28 @@ struct GpuExec {
     }
 
 
+    // Slots for the stash records of ONE wave in ONE returning LDS atomic per counter: `c` = this lane's demand on two
+    // counters, packed (low half: cntA, high half: cntB; a wave asks for far less than 2^16 of either).  A wave scan gives
+    // every lane its offset, lanes 0 and 1 add the wave's totals to the two counters in the same instruction, and the lane's
+    // first slots come back in a / b.  (The per-lane form -- one atomic per record inside a divergent branch -- cost five
+    // dependent LDS round trips per sub-block of phase 1.)  Must be called by every lane of the wave.
+    // enda / endb: one past the last slot of the whole wave (wave-uniform: "does any of this wave's records overflow?").
+    __device__ __forceinline__ void stash_alloc(uint32_t c, uint32_t* cntA, uint32_t* cntB, uint32_t& a, uint32_t& b, uint32_t& enda,
+                                                uint32_t& endb) {
+        constexpr int W = NT < 64 ? NT : 64;
+        const int lane = tid & 63;
+        const uint32_t incl = wave_incl_scan(c);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, W - 1);
+        uint32_t ret = 0;
+        if (lane < 2) ret = atomicAdd(lane == 0 ? cntA : cntB, lane == 0 ? (tot & 0xffffu) : (tot >> 16));
+        const uint32_t ba = (uint32_t)__builtin_amdgcn_readlane((int)ret, 0), bb = (uint32_t)__builtin_amdgcn_readlane((int)ret, W > 1 ? 1 : 0);
+        const uint32_t excl = incl - c;
+        a = ba + (excl & 0xffffu);
+        b = bb + (excl >> 16);
+        enda = ba + (tot & 0xffffu);
+        endb = bb + (tot >> 16);
+    }
+
     __device__ __forceinline__ uint32_t lds_or_nr(uint32_t* p, uint32_t v) { atomicOr(p, v); return 0; }
     __device__ __forceinline__ uint32_t lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
@@ -349,6 +371,14 @@ struct SimExec {
     }
 
 
+    void stash_alloc(uint32_t c, uint32_t* cntA, uint32_t* cntB, uint32_t& a, uint32_t& b, uint32_t& enda, uint32_t& endb) {
+        a = *cntA;  // (threads run one after another: every thread is a "wave" of its own)
+        b = *cntB;
+        *cntA += c & 0xffffu;
+        *cntB += c >> 16;
+        enda = *cntA;
+        endb = *cntB;
+    }
     uint32_t lds_or_nr(uint32_t* p, uint32_t v) {
         *p |= v;
         return 0;

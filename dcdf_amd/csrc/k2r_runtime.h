@@ -73,7 +73,25 @@ struct DevPool {
         blocks.erase(blocks.begin() + (long)best);
         return p;
     }
+    // every kept block back to the driver (out of memory elsewhere in the process; dcdf_device_pool_trim)
+    size_t drain() {
+        std::vector<Blk> all;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            all.swap(blocks);
+            held = 0;
+        }
+        size_t freed = 0;
+        for (const Blk& b : all) {
+            (void)hipFree(b.p);
+            freed += b.n;
+        }
+        return freed;
+    }
     void give(void* p, size_t n) {
+        // hipFree used to order the release behind everything queued on the device; a block parked here may be handed to
+        // another host thread at once, so it must be just as idle (error paths release with copies or kernels still queued)
+        (void)hipDeviceSynchronize();
         std::vector<Blk> drop;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -114,6 +132,10 @@ struct DevBuf {
         release();
         if (n == 0) n = 16;
         hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess && DevPool::enabled() && DevPool::get().drain() > 0) {  // memory idling in the pool: retry once
+            (void)hipGetLastError();
+            e = hipMalloc(&p, n);
+        }
         if (e == hipSuccess) bytes = n;
         else p = nullptr;
         return e;
@@ -138,15 +160,7 @@ struct DevBuf {
         } else {
             p = nullptr;
             if (DevPool::enabled()) {  // out of memory with blocks parked in the pool: give them back and try once more
-                DevPool& pool = DevPool::get();
-                std::vector<DevPool::Blk> all;
-                {
-                    std::lock_guard<std::mutex> lk(pool.mu);
-                    all.swap(pool.blocks);
-                    pool.held = 0;
-                }
-                for (const DevPool::Blk& b : all) (void)hipFree(b.p);
-                if (!all.empty()) {
+                if (DevPool::get().drain() > 0) {
                     (void)hipGetLastError();
                     e = hipMalloc(&p, n);
                     if (e == hipSuccess) {

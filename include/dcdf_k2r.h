@@ -261,6 +261,12 @@ int dcdf_device_alloc(size_t bytes, void** out);
 int dcdf_device_free(void* p);
 int dcdf_device_copy(void* dst, const void* src, size_t bytes, int to_device);
 
+/* The library keeps a few large device blocks between calls (an appending caller asks for the same sizes slice after
+ * slice; hipMalloc / hipFree of gigabytes cost tens of milliseconds).  It gives them back by itself when one of its own
+ * allocations fails; a caller that shares the device with another allocator can return them at any time: the bytes freed
+ * are stored to *freed_bytes (may be NULL).  Environment K2R_POOL=0 disables the pool. */
+int dcdf_device_pool_trim(uint64_t* freed_bytes);
+
 const char* dcdf_strerror(int code);
 /* "gfx950 <device name>, <CUs> CUs" or NULL when no device. */
 const char* dcdf_device_name(void);
