@@ -321,12 +321,12 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
 }
 
 // The compact copy of a block's snapshot instant (see encode_chunk): the 16 cells of sub-block j of thread tid as uint16
-// offsets from `base`, 8 words at [(j * NT + tid) * 8, +8) (a wave reads 2 KB contiguous per sub-block).  Word 4 * p + c holds
+// offsets from `base`, 8 words at [(4 * tid + j) * 8, +8): height-2 nodes in Morton order.  Word 4 * p + c holds
 // cell c of quad 2p (low half) and cell c of quad 2p + 1 (high half): the extremes of two quads then cost three packed
 // 16-bit min / max each, and a difference against an int32 cell reads its half through an operand selector.
 template <class C>
 K2R_HD uint32_t compact_slot(int tid, int j) {
-    return (uint32_t)j * (uint32_t)C::NT + (uint32_t)tid;
+    return 4u * (uint32_t)tid + (uint32_t)j;  // the height-2 node's Morton index (thread = 8x8 block)
 }
 template <class C>
 K2R_HD void load_compact_raw(const uint32_t* scmp, int tid, int j, uint32_t (&w)[8]) {
@@ -596,8 +596,8 @@ struct EncPool {
     // One pool of LDS words with three lives per instant (general path):
     //  (1) phase 1 .. plane-0 emission of a Log: the STASH.  While the cells of a block are in registers, phase 1
     //      records everything the emission of the log candidate will need below height 2 -- one 5-word I record per
-    //      internal height-2 node (growing up from word 0) and one 3-word Q record per internal quad (growing down
-    //      from word POOLW) -- so that emitting a Log touches no input memory at all.
+    //      internal height-2 node (from word 0) and one 3-word Q record per internal quad (from word QBASE) -- so that
+    //      emitting a Log touches no input memory at all.
     //  (2) plane-0 emission of a Snapshot, or of a Log whose stash overflowed / whose values do not fit 16 bits:
     //      the work lists L2 (internal height-2 nodes) and L1 (internal quads) of the re-reading passes.
     //  (3) Dac finishing in list mode: the second continuation bitmap and the rank prefixes of the Lmax Dac.
@@ -610,12 +610,13 @@ struct EncPool {
     static constexpr int POOLFILL = 1828;
 #endif
     static constexpr int POOLW = POOL_PREFV + C::WV + 2 + (C::H == 8 ? POOLFILL : 0);  // sidelen 256: LDS filled to 160 KB
-    // The stash's two record kinds have fixed shares of the pool (I records grow up from word 0, Q records down from POOLW);
+    // The stash's two record kinds have fixed shares of the pool (I records from word 0, Q records from word QBASE);
     // records beyond a share go to a per-workgroup overflow area in global scratch (L2), so an instant with unusually many
     // records -- a snapshot with forced-constant 64x64 blocks makes every quad under them internal -- still takes the stash
     // path (the re-reading fallback is 2.2 x slower per instant, and the 3 % of chunks that hit it set the tail of a launch).
     static constexpr int CAPI_REC = (POOLW * 53 / 100) / 5;
     static constexpr int CAPQ_REC = (POOLW - 5 * CAPI_REC) / 3;
+    static constexpr int QBASE = 5 * CAPI_REC;  // word of Q record 0 (both kinds grow upwards: an address is one multiply-add)
     static constexpr int OVI_WORDS = 5 * 4 * C::NBLK;    // every height-2 node internal
     static constexpr int OVQ_WORDS = 3 * 16 * C::NBLK;   // every quad internal
 };
@@ -1155,170 +1156,252 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 #else
         const bool lean = false;
 #endif
-        if (lean) ex.par([&](int tid, EncRegs& r) {
+        // -- the analysis of one 4x4 sub-block (a height-2 node): t = its 16 cells in local Morton order, w = the copy's --
+        struct LeanSub {
+            uint32_t pq[4];    // per quad: internal for the log (0 / 1)
+            uint32_t recw[4];  // per quad: Lmax | Lmin << 16 of the log (log.rs:133,148), both s_base too large
+            uint32_t qw[8];    // per quad: its four cell differences as two packed words (+ s_base each)
+            uint32_t tb1, e4, su, nq;  // T bits, "equal" bits (first quad = bit 3), non-uniform quads, internal quads
+            uint32_t ne2, nu2, p2;     // the node: not "equal", not uniform, internal for the log (0 / 1 each)
+            uint32_t d2w;              // the node's own Lmax | Lmin << 16 (+ s_base)
+            uint32_t smn2, smx2;       // the snapshot's extremes over the node, as offsets from s_base
+            int32_t mn2, mx2, d0;      // the instant's extremes; the first cell's difference (+ s_base)
+        };
+        auto lean_analyse = [&](const int32_t (&t)[16], const uint32_t (&w)[8], LeanSub& o) {
+            // extremes of the instant's quads and of the node (snapshot.rs:476-497)
+            int32_t mn1[4], mx1[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                mn1[q] = min4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                mx1[q] = max4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+            }
+            o.mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]);
+            o.mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
+            // the same for the snapshot, two quads per packed operation: sn[p] = minima of quads 2p | 2p + 1 << 16
+            uint32_t sn[2], sx[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                sn[p] = pk_min_u16(pk_min_u16(w[4 * p], w[4 * p + 1]), pk_min_u16(w[4 * p + 2], w[4 * p + 3]));
+                sx[p] = pk_max_u16(pk_max_u16(w[4 * p], w[4 * p + 1]), pk_max_u16(w[4 * p + 2], w[4 * p + 3]));
+            }
+            const uint32_t sn2p = pk_min_u16(sn[0], sn[1]), sx2p = pk_max_u16(sx[0], sx[1]);
+            // (opaque: the reductions happen here, not at the end of the block with their inputs spilled in between)
+            o.smn2 = opaque((sn2p & 0xffffu) < (sn2p >> 16) ? (sn2p & 0xffffu) : (sn2p >> 16));
+            o.smx2 = opaque((sx2p & 0xffffu) > (sx2p >> 16) ? (sx2p & 0xffffu) : (sx2p >> 16));
+            // cell differences against the copy (all of them s_base too large: equality tests do not care)
+            int32_t d[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t ww = w[4 * (q >> 1) + c];
+                    d[4 * q + c] = t[4 * q + c] - (int32_t)((q & 1) ? (ww >> 16) : (ww & 0xffffu));
+                }
+            // per quad: "all four differences equal" <=> x == 0 (log.rs:780,805); internal <=> not uniform and not equal.
+            // Flags are 0 / 1 integers made without compares (nz): no mask registers, nothing for the compiler to re-derive.
+            uint32_t x[4];
+            o.tb1 = 0;
+            o.e4 = 0;
+            o.su = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                x[q] = (uint32_t)((d[4 * q] ^ d[4 * q + 1]) | (d[4 * q] ^ d[4 * q + 2]) | (d[4 * q] ^ d[4 * q + 3]));
+                const uint32_t u1 = nz((uint32_t)(mn1[q] ^ mx1[q]));
+                o.pq[q] = u1 & nz(x[q]);               // log.rs:137-152
+                o.tb1 = (o.tb1 << 1) | o.pq[q];
+                o.e4 = (o.e4 << 1) | (u1 ^ o.pq[q]);  // T = 0 and not uniform: "equal" (log.rs:137-144)
+                o.su += u1;
+                const uint32_t sxq = (q & 1) ? (sx[q >> 1] >> 16) : (sx[q >> 1] & 0xffffu);
+                const uint32_t snq = (q & 1) ? (sn[q >> 1] >> 16) : (sn[q >> 1] & 0xffffu);
+                o.recw[q] = pk_lo16((uint32_t)(mx1[q] - (int32_t)sxq), (uint32_t)(mn1[q] - (int32_t)snq));  // log.rs:133,148
+                o.qw[2 * q] = pk_lo16((uint32_t)d[4 * q], (uint32_t)d[4 * q + 1]);
+                o.qw[2 * q + 1] = pk_lo16((uint32_t)d[4 * q + 2], (uint32_t)d[4 * q + 3]);
+            }
+            const uint32_t X = x[0] | x[1] | x[2] | x[3] | (uint32_t)((d[0] ^ d[4]) | (d[0] ^ d[8]) | (d[0] ^ d[12]));
+            // (flags through nz: "== 0" of a long OR-sum is rewritten by the optimizer into a conjunction of compares over every
+            // term, all of them kept alive -- spilled -- until the end of the block)
+            o.ne2 = nz(X);
+            o.nu2 = nz((uint32_t)(o.mn2 ^ o.mx2));
+            o.p2 = o.ne2 & o.nu2;  // log.rs:137-152 for the node
+            o.nq = popc32(o.tb1);
+            o.d0 = d[0];
+            o.d2w = pk_lo16((uint32_t)(o.mx2 - (int32_t)o.smx2), (uint32_t)(o.mn2 - (int32_t)o.smn2));  // log.rs:133,148
+        };
+        // -- its stash records: Q = owner, ordinal among the owner's internal quads, the four cell differences; I = owner, ordinals,
+        //    T bits, "equal" bits and the Lmax|Lmin pairs of the four quads.  ONE allocation for the whole wave. --
+        auto lean_put = [&](const LeanSub& o, uint32_t owner, uint32_t lI1b, uint32_t lI2b) {
+            uint32_t slotQ, slotI, endQ, endI;
+            ex.stash_alloc(o.nq | (o.p2 << 16), &sh.stQ, &sh.stI, slotQ, slotI, endQ, endI);
+            uint32_t ord = lI1b;
+            const uint32_t p0 = owner | (lI2b << 10) | (lI1b << 12) | (o.tb1 << 16) | (o.e4 << 20);
+            if (endQ <= (uint32_t)SH::CAPQ_REC && endI <= (uint32_t)SH::CAPI_REC) {  // (wave-uniform) nothing of this wave overflows
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t* d = sh.pool + ((uint32_t)SH::QBASE + mul24(slotQ, 3u));
+                    if (o.pq[q]) {
+                        d[0] = owner | (ord << 10);
+                        d[1] = o.qw[2 * q];
+                        d[2] = o.qw[2 * q + 1];
+                    }
+                    slotQ += o.pq[q];
+                    ord += o.pq[q];
+                }
+                if (o.p2) {
+                    uint32_t* d = sh.pool + mul24(slotI, 5u);
+                    d[0] = p0;
+                    d[1] = o.recw[0];
+                    d[2] = o.recw[1];
+                    d[3] = o.recw[2];
+                    d[4] = o.recw[3];
+                }
+            } else {  // (separate code paths on purpose: an LDS-or-global pointer would turn both into FLAT stores)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (o.pq[q]) {
+                        if (slotQ < (uint32_t)SH::CAPQ_REC) {
+                            uint32_t* d = sh.pool + (SH::QBASE + 3u * slotQ);
+                            d[0] = owner | (ord << 10);
+                            d[1] = o.qw[2 * q];
+                            d[2] = o.qw[2 * q + 1];
+                        } else {
+                            gstore_words3(ovQ + 3u * (slotQ - (uint32_t)SH::CAPQ_REC), owner | (ord << 10), o.qw[2 * q], o.qw[2 * q + 1]);
+                        }
+                    }
+                    slotQ += o.pq[q];
+                    ord += o.pq[q];
+                }
+                if (o.p2) {
+                    if (slotI < (uint32_t)SH::CAPI_REC) {
+                        uint32_t* d = sh.pool + 5u * slotI;
+                        d[0] = p0;
+                        d[1] = o.recw[0];
+                        d[2] = o.recw[1];
+                        d[3] = o.recw[2];
+                        d[4] = o.recw[3];
+                    } else {
+                        gstore_words5(ovI + 5u * (slotI - (uint32_t)SH::CAPI_REC), p0, o.recw[0], o.recw[1], o.recw[2], o.recw[3]);
+                    }
+                }
+            }
+        };
+        // what the owner of a block keeps of it, and what goes to the top arrays
+        auto lean_block_out = [&](uint32_t B, int32_t mn3, int32_t mx3, uint32_t smn3, uint32_t smx3, int32_t dref, uint32_t Zb, uint32_t& wide,
+                                  int32_t& err, bool store) {
+            // raw int32 rows are not range-checked cell by cell: the block's extremes decide (value-range contract)
+            if (VEC == 1 && (mn3 < -VALUE_LIMIT || mx3 >= VALUE_LIMIT) && err == 0) err = ERR_RANGE;
+            const int32_t smn3t = s_base + (int32_t)smn3, smx3t = s_base + (int32_t)smx3;
+            // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: below 2^15 in magnitude none of them needs a
+            // third byte (and the 16 bits kept of each are all of it); otherwise the exact classes_pass is requested
+            wide = (mn3 - smx3t < -32768 || mx3 - smn3t > 32767) ? 1u : 0u;
+            if (store) {
+                sh.tmin[B] = mn3;
+                sh.tmax[B] = mx3;
+                sh.smin[B] = smn3t;
+                sh.smax[B] = smx3t;
+                sh.diff[B] = dref - s_base;
+                sh.eq[B] = Zb == 0 ? 1u : 0u;
+                sh.lq[B][0] = 0;
+                sh.lq[B][1] = 0;
+                sh.li[B] = 0;
+            }
+        };
+        if (lean && !EX::kSim) {
+            // The GPU form.  A lane owns a SUB-BLOCK: in pass p = 0..3 the wave covers 64 Morton-consecutive height-2 nodes, lanes
+            // 4b .. 4b+3 the four of one block -- so eight lanes read 128 contiguous bytes of a row (a lane that owns an 8x8 block
+            // reads 16 bytes of every other 32, and each line is fetched twice: profiles/r04d), and the wave's records enter the
+            // stash in level order, which is what lets the emission passes' stores coalesce (profiles/r04e: 16 instead of up to 350
+            // cycles per store instruction).  Block-level results are reduced over the quad with DPP and pulled by the lane that
+            // owns the block in the rest of the kernel (thread = block) with ds_bpermute.
+            if constexpr (!EX::kSim) ex.par([&](int tid, EncRegs& r) {
+                constexpr uint32_t NTW = NT < 64 ? NT : 64, BPP = NTW / 4;  // lanes per wave, blocks per pass and wave
+                const uint32_t ltid = opaque((uint32_t)tid), lane = ltid & 63u, j = lane & 3u;
+                int32_t err = 0;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    sched_fence();
+                    const uint32_t B = (ltid & ~63u) + BPP * (uint32_t)p + (lane >> 2);  // the block, and its owner's thread index
+                    uint32_t br, bc;
+                    morton_decode(4u * B + j, br, bc);
+                    int32_t t[16];
+                    uint32_t w[8];
+                    load_sub16<false, VEC>(ta, inst, 4u * br, 4u * bc, 0, t, err);
+                    // (settled here: left symbolic, the range / conversion checks of all four passes are evaluated at the end of
+                    // the phase, with every raw cell they look at kept alive -- spilled -- until then)
+                    if (VEC >= 2) err = (int32_t)opaque((uint32_t)err);
+                    load_compact_raw<C>(cmp, (int)B, (int)j, w);
+                    LeanSub o;
+                    lean_analyse(t, w, o);
+                    sched_fence();
+                    // the block: counts of the sub-blocks before this one, extremes, "equal"
+                    const uint32_t cnt = o.nq | (o.p2 << 8) | (o.su << 16) | (o.nu2 << 24);
+                    const uint32_t n0 = EX::template quad_bcast<0>(cnt), n1 = EX::template quad_bcast<1>(cnt), n2 = EX::template quad_bcast<2>(cnt),
+                                   n3 = EX::template quad_bcast<3>(cnt);
+                    const uint32_t pre = (j > 0 ? n0 : 0u) + (j > 1 ? n1 : 0u) + (j > 2 ? n2 : 0u), tot = n0 + n1 + n2 + n3;
+                    lean_put(o, B, pre & 0xffu, (pre >> 8) & 0xffu);
+                    const int32_t mn3 = EX::quad_min(o.mn2), mx3 = EX::quad_max(o.mx2);
+                    const uint32_t smn3 = (uint32_t)EX::quad_min((int32_t)o.smn2), smx3 = (uint32_t)EX::quad_max((int32_t)o.smx2);
+                    const int32_t dref = (int32_t)EX::template quad_bcast<0>((uint32_t)o.d0);
+                    const uint32_t Zb = EX::quad_or(o.ne2 | nz((uint32_t)(o.d0 ^ dref)));
+                    uint32_t wide;
+                    lean_block_out(B, mn3, mx3, smn3, smx3, dref, Zb, wide, err, j == 0);
+                    // the owner's registers (k2r EncRegs): flags = eq2 bits | internal quads per sub-block (snapshot, log) | wide
+                    const uint32_t fw = EX::quad_or(((o.ne2 ^ 1u) << j) | (o.su << (4u + 3u * j)) | (o.nq << (16u + 3u * j))) | (wide << 28);
+                    const uint32_t uw = EX::quad_or((o.nu2 ^ 1u) << j);
+                    const uint32_t own_lane = lane - BPP * (uint32_t)p, src = (4u * own_lane) & 63u;  // (meaningful for the owners of this pass)
+                    const uint32_t g0 = EX::lane_pull(src, o.d2w), g1 = EX::lane_pull(src + 1u, o.d2w), g2 = EX::lane_pull(src + 2u, o.d2w),
+                                   g3 = EX::lane_pull(src + 3u, o.d2w);
+                    const uint32_t gf = EX::lane_pull(src, fw), gu = EX::lane_pull(src, uw), gt = EX::lane_pull(src, tot);
+                    if (lane / BPP == (uint32_t)p) {
+                        r.d2[0] = g0;
+                        r.d2[1] = g1;
+                        r.d2[2] = g2;
+                        r.d2[3] = g3;
+                        r.flags = gf;
+                        r.u2 = gu;
+                        r.sc[0] = ((gt >> 16) & 0xffu) | ((gt >> 24) << 16);   // snapshot I1 | I2 << 16
+                        r.sc[3] = (gt & 0xffu) | (((gt >> 8) & 0xffu) << 16);  // log I1 | I2 << 16
+                    }
+                }
+                if (tid < C::TBW) {
+                    sh.tbS[tid] = 0;
+                    sh.tbL[tid] = 0;
+                }
+                if (err != 0) ex.lds_min(&sh.err, err);
+            });
+        } else if (lean) ex.par([&](int tid, EncRegs& r) {  // the same with thread = block (the sequential context of tests/sim)
             uint32_t r0, c0;
             blk_origin(tid, r0, c0);
-            const uint32_t ltid = opaque((uint32_t)tid);  // (anything derived from the thread index must not be hoisted: see opaque)
             int32_t err = 0;
-            sh.lq[ltid][0] = 0;
-            sh.lq[ltid][1] = 0;
-            sh.li[ltid] = 0;
             uint32_t sI1 = 0, sI2 = 0, lI1 = 0, lI2 = 0, eqbits = 0, cntbits = 0, u2 = 0, Z = 0;
             int32_t mn3 = 0, mx3 = 0, dref = 0;
             uint32_t smn3 = 0, smx3 = 0;  // the snapshot's extremes as offsets from s_base, like the copy's cells
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                sched_fence();
                 int32_t t[16];
                 uint32_t w[8];
                 load_sub16<false, VEC>(ta, inst, r0, c0, j, t, err);
-                load_compact_raw<C>(cmp, (int)ltid, j, w);
-                // extremes of the instant's quads and of the node (snapshot.rs:476-497)
-                int32_t mn1[4], mx1[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    mn1[q] = min4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
-                    mx1[q] = max4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
-                }
-                const int32_t mn2 = min4(mn1[0], mn1[1], mn1[2], mn1[3]), mx2 = max4(mx1[0], mx1[1], mx1[2], mx1[3]);
-                // the same for the snapshot, two quads per packed operation: sn[p] = minima of quads 2p | 2p + 1 << 16
-                uint32_t sn[2], sx[2];
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    sn[p] = pk_min_u16(pk_min_u16(w[4 * p], w[4 * p + 1]), pk_min_u16(w[4 * p + 2], w[4 * p + 3]));
-                    sx[p] = pk_max_u16(pk_max_u16(w[4 * p], w[4 * p + 1]), pk_max_u16(w[4 * p + 2], w[4 * p + 3]));
-                }
-                const uint32_t sn2p = pk_min_u16(sn[0], sn[1]), sx2p = pk_max_u16(sx[0], sx[1]);
-                // (opaque: the reductions happen here, not at the end of the block with their inputs spilled in between)
-                const uint32_t smn2 = opaque((sn2p & 0xffffu) < (sn2p >> 16) ? (sn2p & 0xffffu) : (sn2p >> 16));
-                const uint32_t smx2 = opaque((sx2p & 0xffffu) > (sx2p >> 16) ? (sx2p & 0xffffu) : (sx2p >> 16));
-                sched_fence();
-                // cell differences against the copy (all of them s_base too large: equality tests do not care)
-                int32_t d[16];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const uint32_t ww = w[4 * (q >> 1) + c];
-                        d[4 * q + c] = t[4 * q + c] - (int32_t)((q & 1) ? (ww >> 16) : (ww & 0xffffu));
-                    }
-                // per quad: "all four differences equal" <=> x == 0 (log.rs:780,805); internal <=> not uniform and not equal.
-                // Flags are 0 / 1 integers made without compares (nz): no mask registers, nothing for the compiler to re-derive.
-                uint32_t x[4], recw[4], pq[4], tb1 = 0, e4 = 0, su = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    x[q] = (uint32_t)((d[4 * q] ^ d[4 * q + 1]) | (d[4 * q] ^ d[4 * q + 2]) | (d[4 * q] ^ d[4 * q + 3]));
-                    const uint32_t u1 = nz((uint32_t)(mn1[q] ^ mx1[q]));
-                    pq[q] = u1 & nz(x[q]);               // log.rs:137-152
-                    tb1 = (tb1 << 1) | pq[q];
-                    e4 = (e4 << 1) | (u1 ^ pq[q]);      // T = 0 and not uniform: "equal" (log.rs:137-144)
-                    su += u1;
-                    const uint32_t sxq = (q & 1) ? (sx[q >> 1] >> 16) : (sx[q >> 1] & 0xffffu);
-                    const uint32_t snq = (q & 1) ? (sn[q >> 1] >> 16) : (sn[q >> 1] & 0xffffu);
-                    recw[q] = pk_lo16((uint32_t)(mx1[q] - (int32_t)sxq), (uint32_t)(mn1[q] - (int32_t)snq));  // log.rs:133,148 (+ s_base)
-                }
-                const uint32_t X = x[0] | x[1] | x[2] | x[3] | (uint32_t)((d[0] ^ d[4]) | (d[0] ^ d[8]) | (d[0] ^ d[12]));
-                const uint32_t ne2 = nz(X), nu2 = nz((uint32_t)(mn2 ^ mx2)), p2 = ne2 & nu2;  // P2L
-                if (j == 0) dref = d[0];
-                // (through nz: left as one OR-sum the optimizer rewrites "== 0" of it into a conjunction of compares over every
-                // term, all of them kept alive -- spilled -- until the end of the block)
-                Z |= ne2 | nz((uint32_t)(d[0] ^ dref));
-                sched_fence();
-                // stash: the wave's records of this sub-block in one allocation
-                const uint32_t nq = popc32(tb1);
-                uint32_t slotQ, slotI, endQ, endI;
-                ex.stash_alloc(nq | (p2 << 16), &sh.stQ, &sh.stI, slotQ, slotI, endQ, endI);
-                uint32_t ord = lI1;
-                // Q record: owner, ordinal among the owner's internal quads, the four cell differences;
-                // I record: owner, ordinals, T bits, eqB bits and the Lmax|Lmin pairs of the four quads
-                const uint32_t p0 = ltid | (lI2 << 10) | (lI1 << 12) | (tb1 << 16) | (e4 << 20);
-                if (endQ <= (uint32_t)SH::CAPQ_REC && endI <= (uint32_t)SH::CAPI_REC) {  // (wave-uniform) nothing of this wave overflows
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t q0 = ltid | (ord << 10);
-                        const uint32_t q1 = pk_lo16((uint32_t)d[4 * q], (uint32_t)d[4 * q + 1]), q2 = pk_lo16((uint32_t)d[4 * q + 2], (uint32_t)d[4 * q + 3]);
-                        uint32_t* o = sh.pool + ((uint32_t)SH::POOLW - 3u - mul24(slotQ, 3u));
-                        if (pq[q]) {
-                            o[0] = q0;
-                            o[1] = q1;
-                            o[2] = q2;
-                        }
-                        slotQ += pq[q];
-                        ord += pq[q];
-                    }
-                    if (p2) {
-                        uint32_t* o = sh.pool + mul24(slotI, 5u);
-                        o[0] = p0;
-                        o[1] = recw[0];
-                        o[2] = recw[1];
-                        o[3] = recw[2];
-                        o[4] = recw[3];
-                    }
-                } else {  // (separate code paths on purpose: an LDS-or-global pointer would turn both into FLAT stores)
-#pragma unroll 1
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t q0 = ltid | (ord << 10);
-                        const uint32_t dd[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
-                        const uint32_t q1 = pk_lo16(dd[0], dd[1]), q2 = pk_lo16(dd[2], dd[3]);
-                        if (pq[0]) {
-                            if (slotQ < (uint32_t)SH::CAPQ_REC) {
-                                uint32_t* o = sh.pool + (SH::POOLW - 3u * (slotQ + 1u));
-                                o[0] = q0;
-                                o[1] = q1;
-                                o[2] = q2;
-                            } else {
-                                gstore_words3(ovQ + 3u * (slotQ - (uint32_t)SH::CAPQ_REC), q0, q1, q2);
-                            }
-                        }
-                        slotQ += pq[0];
-                        ord += pq[0];
-                        // next quad into place (a rolled loop: this path is cold, its code should be small)
-                        pq[0] = pq[1]; pq[1] = pq[2]; pq[2] = pq[3];
-#pragma unroll
-                        for (int i = 0; i < 12; i++) d[i] = d[i + 4];
-                    }
-                    if (p2) {
-                        if (slotI < (uint32_t)SH::CAPI_REC) {
-                            uint32_t* o = sh.pool + 5u * slotI;
-                            o[0] = p0;
-                            o[1] = recw[0];
-                            o[2] = recw[1];
-                            o[3] = recw[2];
-                            o[4] = recw[3];
-                        } else {
-                            gstore_words5(ovI + 5u * (slotI - (uint32_t)SH::CAPI_REC), p0, recw[0], recw[1], recw[2], recw[3]);
-                        }
-                    }
-                }
-                sched_fence();
-                const bool un2 = nu2 == 0, eq2 = ne2 == 0;
-                const uint32_t P2Lc = p2;
-                sI1 += su;
-                sI2 += nu2;
-                cntbits |= (su << (4 + 3 * j)) | (nq << (16 + 3 * j));
-                lI1 += nq;
-                lI2 += P2Lc;
-                u2 |= (un2 ? 1u : 0u) << j;
-                eqbits |= (eq2 ? 1u : 0u) << j;
-                r.d2[j] = pk_lo16((uint32_t)(mx2 - (int32_t)smx2), (uint32_t)(mn2 - (int32_t)smn2));  // log.rs:133,148 (+ s_base)
-                mn3 = j == 0 ? mn2 : (mn2 < mn3 ? mn2 : mn3);
-                mx3 = j == 0 ? mx2 : (mx2 > mx3 ? mx2 : mx3);
-                smn3 = j == 0 ? smn2 : (smn2 < smn3 ? smn2 : smn3);
-                smx3 = j == 0 ? smx2 : (smx2 > smx3 ? smx2 : smx3);
+                load_compact_raw<C>(cmp, tid, j, w);
+                LeanSub o;
+                lean_analyse(t, w, o);
+                if (j == 0) dref = o.d0;
+                Z |= o.ne2 | nz((uint32_t)(o.d0 ^ dref));
+                lean_put(o, (uint32_t)tid, lI1, lI2);
+                sI1 += o.su;
+                sI2 += o.nu2;
+                cntbits |= (o.su << (4 + 3 * j)) | (o.nq << (16 + 3 * j));
+                lI1 += o.nq;
+                lI2 += o.p2;
+                u2 |= (o.nu2 ^ 1u) << j;
+                eqbits |= (o.ne2 ^ 1u) << j;
+                r.d2[j] = o.d2w;
+                mn3 = j == 0 ? o.mn2 : (o.mn2 < mn3 ? o.mn2 : mn3);
+                mx3 = j == 0 ? o.mx2 : (o.mx2 > mx3 ? o.mx2 : mx3);
+                smn3 = j == 0 ? o.smn2 : (o.smn2 < smn3 ? o.smn2 : smn3);
+                smx3 = j == 0 ? o.smx2 : (o.smx2 > smx3 ? o.smx2 : smx3);
             }
-            // raw int32 rows are not range-checked cell by cell: the block's extremes decide (value-range contract)
-            if (VEC == 1 && (mn3 < -VALUE_LIMIT || mx3 >= VALUE_LIMIT) && err == 0) err = ERR_RANGE;
-            sh.tmin[tid] = mn3;
-            sh.tmax[tid] = mx3;
+            uint32_t wide;
+            lean_block_out((uint32_t)tid, mn3, mx3, smn3, smx3, dref, Z, wide, err, true);
             r.sc[0] = sI1 | (sI2 << 16);
-            const int32_t smn3t = s_base + (int32_t)smn3, smx3t = s_base + (int32_t)smx3;
-            // every in-block log value lies in [mn3 - smx3, mx3 - smn3]: below 2^15 in magnitude none of them needs a
-            // third byte (and the 16 bits kept of each are all of it); otherwise the exact classes_pass is requested
-            const uint32_t wide = (mn3 - smx3t < -32768 || mx3 - smn3t > 32767) ? 1u : 0u;
-            sh.smin[tid] = smn3t;
-            sh.smax[tid] = smx3t;
-            sh.diff[tid] = dref - s_base;
-            sh.eq[tid] = Z == 0 ? 1u : 0u;
             r.flags = eqbits | cntbits | (wide << 28);
             r.u2 = u2;
             if (tid < C::TBW) {
@@ -1405,7 +1488,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                             const uint32_t q1 = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16);
                             const uint32_t q2 = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
                             if (m < (uint32_t)SH::CAPQ_REC) {
-                                uint32_t* q = sh.pool + (SH::POOLW - 3u * (m + 1u));
+                                uint32_t* q = sh.pool + (SH::QBASE + 3u * m);
                                 q[0] = q0;
                                 q[1] = q1;
                                 q[2] = q2;
@@ -1498,7 +1581,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     uint32_t q[3];
                     if (m < (uint32_t)SH::CAPQ_REC) {
 #pragma unroll
-                        for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::POOLW - 3u * (m + 1u) + i];
+                        for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::QBASE + 3u * m + i];
                     } else {
                         gload_words<3>(ovQ + 3u * (m - (uint32_t)SH::CAPQ_REC), q);
                     }
@@ -2210,7 +2293,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     uint32_t q[3];
                     if (!OVF || m < (uint32_t)SH::CAPQ_REC) {
 #pragma unroll
-                        for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::POOLW - 3u * (m + 1u) + i];
+                        for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::QBASE + 3u * m + i];
                     } else {
                         gload_words<3>(ovQ + 3u * (m - (uint32_t)SH::CAPQ_REC), q);
                     }

@@ -253,6 +253,35 @@ struct GpuExec {
     }
 
 
+    // Lanes 4q .. 4q+3 of a wave form a quad (DPP quad_perm: no LDS, full rate).  quad_perm<CTRL>: lane i of a quad reads lane
+    // (CTRL >> 2i) & 3 of the same quad; the reductions leave the result in all four lanes.
+    template <int CTRL>
+    __device__ __forceinline__ static uint32_t quad_perm(uint32_t v) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+    }
+    template <int K>
+    __device__ __forceinline__ static uint32_t quad_bcast(uint32_t v) { return quad_perm<K * 0x55>(v); }
+    __device__ __forceinline__ static int32_t quad_min(int32_t x) {
+        int32_t y = (int32_t)quad_perm<0xB1>((uint32_t)x);
+        x = x < y ? x : y;
+        y = (int32_t)quad_perm<0x4E>((uint32_t)x);
+        return x < y ? x : y;
+    }
+    __device__ __forceinline__ static int32_t quad_max(int32_t x) {
+        int32_t y = (int32_t)quad_perm<0xB1>((uint32_t)x);
+        x = x > y ? x : y;
+        y = (int32_t)quad_perm<0x4E>((uint32_t)x);
+        return x > y ? x : y;
+    }
+    __device__ __forceinline__ static uint32_t quad_or(uint32_t x) {
+        x |= quad_perm<0xB1>(x);
+        return x | quad_perm<0x4E>(x);
+    }
+    // the value v of lane `src` (0..63) of this wave (ds_bpermute: the LDS crossbar, no LDS memory)
+    __device__ __forceinline__ static uint32_t lane_pull(uint32_t src, uint32_t v) {
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+    }
+
     // Slots for the stash records of ONE wave in ONE returning LDS atomic per counter: `c` = this lane's demand on two
     // counters, packed (low half: cntA, high half: cntB; a wave asks for far less than 2^16 of either).  A wave scan gives
     // every lane its offset, lanes 0 and 1 add the wave's totals to the two counters in the same instruction, and the lane's
