@@ -36,6 +36,17 @@
 #pragma once
 #include "k2r_exec.h"
 
+// -DK2R_REGCOPY: the open block's compact snapshot copy lives in registers (EncRegs::cw) instead of global scratch -- no re-read
+// of 128 KB per instant, but 32 of the 128 VGPRs gone for every phase: built, bit-exact, and 27 % SLOWER (95 spilled VGPRs; 14.2
+// against 11.2 ms), so it is off.
+
+// -DK2R_DIAG_SKIP=<bits>: timing-only builds that leave a phase of the stash-log path out (the output is WRONG; every store
+// position stays clamped, so it is memory-safe): what a phase costs on the critical path is the time its removal saves.
+//   1 pass A   2 I records   4 Q records   8 bitmaps   16 second bytes of the top nodes   32 zero bitmaps   64 pre-pass
+#ifndef K2R_DIAG_SKIP
+#define K2R_DIAG_SKIP 0
+#endif
+
 namespace k2r {
 
 template <int LOG2S>
@@ -71,6 +82,13 @@ struct EncRegs {
     uint64_t pf_lo;                // saved exclusive prefix of the chosen candidate's lo pack
     uint32_t pf_l2;                // second bytes before this block's height-2 group (Lmax | Lmin << 16)
     uint32_t pa[5];                // what pass A emitted for nodes of heights >= 3 (positions, second bytes), replayed later
+#ifdef K2R_REGCOPY
+    // The compact copy of the open block's snapshot instant (unpadded tiles): 64 cells of this thread as packed uint16 offsets
+    // from s_base, in the layout of store_compact -- 128 KB per workgroup that are compared with every later instant of the block
+    // and would otherwise be fetched again for each (a third of phase 1's bytes, a quarter of the kernel's HBM traffic).
+    // GPU: words [8p, 8p+8) = the sub-block this lane analyses in pass p of phase 1; sequential context: sub-block j = p of its block.
+    uint32_t cw[32];
+#endif
 };
 
 // ---- packed scan fields ------------------------------------------------------------------
@@ -294,7 +312,14 @@ K2R_HD void load_sub16(const TileArgs& ta, uint32_t inst, uint32_t r0, uint32_t 
 #if defined(__HIP_DEVICE_COMPILE__)
             typedef __attribute__((address_space(1))) const char* gptr;
             const uint32_t ob = o << 2;  // 32-bit BYTE offset (< 2^31 by the host's VEC test): "saddr + voffset" form
+#ifdef K2R_NT_LOADS
+            // the instant's cells are read once: streamed past the caches, so that what IS re-read (the snapshot copy) stays in L2
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            const i4v av = __builtin_nontemporal_load((__attribute__((address_space(1))) const i4v*)((gptr)ib + ob));
+            const int4 a = {av.x, av.y, av.z, av.w};
+#else
             const int4 a = *(__attribute__((address_space(1))) const int4*)((gptr)ib + ob);
+#endif
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
 #else
             for (int i = 0; i < 4; i++) v[i] = ib[o + i];
@@ -1111,19 +1136,63 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 #endif
 
     // the compact copy of instant `from` (the open block's snapshot) for the logs that follow
-    auto compact_pass = [&](uint32_t from) {
-        ex.par_nosync([&](int tid, EncRegs&) {
-            uint32_t r0, c0;
-            blk_origin(tid, r0, c0);
-            int32_t lerr = 0;
+#ifdef K2R_REGCOPY
+    constexpr bool kRegCopy = !PADDED;
+#else
+    constexpr bool kRegCopy = false;
+#endif
+    // sub-block (of a thread's phase-1 pass p) -> height-2 node and owner block, in the mapping of the lean phase 1
+    auto lean_node = [&](uint32_t ltid, int p, uint32_t& B, uint32_t& j) {
+        if (EX::kSim) {
+            B = ltid;
+            j = (uint32_t)p;
+        } else {
+            constexpr uint32_t NTW = NT < 64 ? NT : 64, BPP = NTW / 4;  // lanes per wave, blocks per pass and wave
+            const uint32_t lane = ltid & 63u;
+            B = (ltid & ~63u) + BPP * (uint32_t)p + (lane >> 2);
+            j = lane & 3u;
+        }
+    };
+    auto compact_pass = [&](uint32_t from, bool to_global) {
+        if (kRegCopy) {
+#ifdef K2R_REGCOPY
+            ex.par_nosync([&](int tid, EncRegs& r) {
+                const uint32_t ltid = opaque((uint32_t)tid);
+                int32_t lerr = 0;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    uint32_t B, j, br, bc;
+                    lean_node(ltid, p, B, j);
+                    morton_decode(4u * B + j, br, bc);
+                    int32_t t16[16];
+                    load_sub16<false, VEC>(ta, from, 4u * br, 4u * bc, 0, t16, lerr);
+#pragma unroll
+                    for (int q = 0; q < 2; q++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+                            r.cw[8 * p + 4 * q + c] = (uint32_t)(t16[8 * q + c] - s_base) | ((uint32_t)(t16[8 * q + 4 + c] - s_base) << 16);
+                    if (to_global) {  // (the first part of a chunk encoded in parts: the continuations fetch their copy from here)
+                        uint32_t* g = cmp + (size_t)compact_slot<C>((int)B, (int)j) * 8;
+                        for (int i = 0; i < 8; i++) g[i] = r.cw[8 * p + i];
+                    }
+                }
+            });
+            if (to_global) ex.barrier_global();
+#endif
+        } else {
+            ex.par_nosync([&](int tid, EncRegs&) {
+                uint32_t r0, c0;
+                blk_origin(tid, r0, c0);
+                int32_t lerr = 0;
 #pragma unroll 1
-            for (int j = 0; j < 4; j++) {
-                int32_t t16[16];
-                load_sub16<PADDED, VEC>(ta, from, r0, c0, j, t16, lerr);
-                store_compact<C>(cmp, tid, j, s_base, t16);
-            }
-        });
-        ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
+                for (int j = 0; j < 4; j++) {
+                    int32_t t16[16];
+                    load_sub16<PADDED, VEC>(ta, from, r0, c0, j, t16, lerr);
+                    store_compact<C>(cmp, tid, j, s_base, t16);
+                }
+            });
+            ex.barrier_global();  // the stores are read back (by the same threads) in the next instant's phase 1
+        }
     };
 
     if (cont) {  // the open block as the first part left it: instant 0 is its snapshot
@@ -1134,8 +1203,23 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         s_idx = 0;
         blk_count = i_begin;
         cmp = ta.shared_cmp;
-        ex.par([&](int tid, EncRegs&) {
+        ex.par([&](int tid, EncRegs& r) {
             if (tid == 0) sh.err = 0;
+#ifdef K2R_REGCOPY
+            if (kRegCopy && s_cmp) {
+                const uint32_t ltid = opaque((uint32_t)tid);
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    uint32_t B, j, w[8];
+                    lean_node(ltid, p, B, j);
+                    load_compact_raw<C>(cmp, (int)B, (int)j, w);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) r.cw[8 * p + i] = w[i];
+                }
+            }
+#else
+            (void)r;
+#endif
         });
     }
 
@@ -1316,19 +1400,43 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 constexpr uint32_t NTW = NT < 64 ? NT : 64, BPP = NTW / 4;  // lanes per wave, blocks per pass and wave
                 const uint32_t ltid = opaque((uint32_t)tid), lane = ltid & 63u, j = lane & 3u;
                 int32_t err = 0;
+                // (the next pass's cells are requested before this pass's are analysed: K2R_LEAN_PREFETCH)
+                int32_t tn[16];
+                uint32_t wn[8];
+                auto request = [&](int p, int32_t (&tt)[16], uint32_t (&ww)[8]) {
+                    const uint32_t Bp = (ltid & ~63u) + BPP * (uint32_t)p + (lane >> 2);
+                    uint32_t br, bc;
+                    morton_decode(4u * Bp + j, br, bc);
+                    load_sub16<false, VEC>(ta, inst, 4u * br, 4u * bc, 0, tt, err);
+                    // (settled here: left symbolic, the range / conversion checks of all four passes are evaluated at the end of
+                    // the phase, with every raw cell they look at kept alive -- spilled -- until then)
+                    if (VEC >= 2) err = (int32_t)opaque((uint32_t)err);
+#ifdef K2R_REGCOPY
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ww[i] = r.cw[8 * p + i];
+#else
+                    load_compact_raw<C>(cmp, (int)Bp, (int)j, ww);
+#endif
+                };
+#ifdef K2R_LEAN_PREFETCH
+                request(0, tn, wn);
+#endif
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     sched_fence();
                     const uint32_t B = (ltid & ~63u) + BPP * (uint32_t)p + (lane >> 2);  // the block, and its owner's thread index
-                    uint32_t br, bc;
-                    morton_decode(4u * B + j, br, bc);
                     int32_t t[16];
                     uint32_t w[8];
-                    load_sub16<false, VEC>(ta, inst, 4u * br, 4u * bc, 0, t, err);
-                    // (settled here: left symbolic, the range / conversion checks of all four passes are evaluated at the end of
-                    // the phase, with every raw cell they look at kept alive -- spilled -- until then)
-                    if (VEC >= 2) err = (int32_t)opaque((uint32_t)err);
-                    load_compact_raw<C>(cmp, (int)B, (int)j, w);
+#ifdef K2R_LEAN_PREFETCH
+#pragma unroll
+                    for (int i = 0; i < 16; i++) t[i] = tn[i];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) w[i] = wn[i];
+                    if (p < 3) request(p + 1, tn, wn);
+                    sched_fence();
+#else
+                    request(p, t, w);
+#endif
                     LeanSub o;
                     lean_analyse(t, w, o);
                     sched_fence();
@@ -1380,7 +1488,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 int32_t t[16];
                 uint32_t w[8];
                 load_sub16<false, VEC>(ta, inst, r0, c0, j, t, err);
+#ifdef K2R_REGCOPY
+                for (int i = 0; i < 8; i++) w[i] = r.cw[8 * j + i];
+#else
                 load_compact_raw<C>(cmp, tid, j, w);
+#endif
                 LeanSub o;
                 lean_analyse(t, w, o);
                 if (j == 0) dref = o.d0;
@@ -1576,7 +1688,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         if (have_s) {
             // records that overflowed to global scratch are read by other threads: their stores must have landed
             if (rec_ovf) ex.barrier_global();
-            ex.par_nosync([&](int tid, EncRegs&) {
+            if (!(K2R_DIAG_SKIP & 64)) ex.par_nosync([&](int tid, EncRegs&) {
                 for (uint32_t m = (uint32_t)tid; m < stQ; m += NT) {
                     uint32_t q[3];
                     if (m < (uint32_t)SH::CAPQ_REC) {
@@ -2224,7 +2336,7 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
             // one visit of each source (EM_ONE), except the second bytes of the few nodes of heights >= 3 ----
             // Pass A and the two stash passes only write output bytes and OR bits into the LDS bitmaps: nothing one of them
             // produces is read by another, so a wave runs through all three without waiting for the others.
-            passA(EmTag<EM_P0>{});
+            if (!(K2R_DIAG_SKIP & 1)) passA(EmTag<EM_P0>{});
             ex.stamp(10);
             // one work item per I record: the four height-1 children of an internal height-2 node.  Records are in
             // arrival order; their place in level order comes from the owner's prefixes.
@@ -2281,7 +2393,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 guard_flush(ex);
               });
             };
-            if (rec_ovf) passI(EmTag<1>{});
+            if (K2R_DIAG_SKIP & 2) {
+            } else if (rec_ovf) passI(EmTag<1>{});
             else passI(EmTag<0>{});
             ex.stamp(11);
             // one work item per Q record: the four cells of an internal quad
@@ -2310,7 +2423,8 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 guard_flush(ex);
               });
             };
-            if (rec_ovf) passQ(EmTag<1>{});
+            if (K2R_DIAG_SKIP & 4) ex.barrier();
+            else if (rec_ovf) passQ(EmTag<1>{});
             else passQ(EmTag<0>{});
             ex.stamp(6);
             // T, eqB and the continuation bitmaps of both Dacs (serialized; rank prefixes kept for the top nodes)
@@ -2320,12 +2434,12 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                                        {sh.bmE, lt - m0, nullptr, 0, io + log_eq_off},
                                        {sh.bmV0, sinkV.n0, sh.prefTopV, SH::PREFTOP, nlevV > 0 ? io + ex.uni(DV.bm_off[0]) : nullptr},
                                        {sh.bmM[0], sinkM.n0, sh.prefM, SH::PREFTOP, nlevM > 0 ? io + ex.uni(DM.bm_off[0]) : nullptr}};
-                bitmaps_finish<C, 4>(ex, jobs);
+                if (!(K2R_DIAG_SKIP & 8)) bitmaps_finish<C, 4>(ex, jobs);
             }
             ex.stamp(8);
             if (nlevV > 1 || nlevM > 1) {
                 // second bytes of the nodes of heights >= 3, replayed from the registers pass A left behind
-                ex.par_nosync([&](int tid, EncRegs& r) {
+                if (!(K2R_DIAG_SKIP & 16)) ex.par_nosync([&](int tid, EncRegs& r) {
                     auto put = [&](const DacSink& d, uint32_t* bm0, uint32_t pos, uint32_t hi) {
                         if (hi) {
                             pos = guard_pos(ex, pos, 1, d.n0 < 32u * SH::PREFTOP ? d.n0 : 32u * SH::PREFTOP, d.code);
@@ -2340,13 +2454,13 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     guard_flush(ex);
                 });
                 ex.stamp(14);
-                if (nlevV > 1) bitmap_write_zero<C>(ex, sinkV.n1, io + ex.uni(DV.bm_off[1]));
-                if (nlevM > 1) bitmap_write_zero<C>(ex, sinkM.n1, io + ex.uni(DM.bm_off[1]));
+                if (nlevV > 1 && !(K2R_DIAG_SKIP & 32)) bitmap_write_zero<C>(ex, sinkV.n1, io + ex.uni(DV.bm_off[1]));
+                if (nlevM > 1 && !(K2R_DIAG_SKIP & 32)) bitmap_write_zero<C>(ex, sinkM.n1, io + ex.uni(DM.bm_off[1]));
                 // (no barrier: nothing the next instant's first phase writes is read above)
             }
             ex.stamp(9);
         } else {
-            if (as_snapshot && s_cmp) compact_pass(inst);  // leave the compact copy of this snapshot instant for the logs that follow
+            if (as_snapshot && s_cmp) compact_pass(inst, head && inst == 0);  // leave the compact copy of this snapshot instant for the logs that follow
             if (head && inst == 0) {  // ... and for the parts that continue this chunk
                 ex.publish(ta.shared_flag, s_cmp ? PART_CMP : PART_NOCMP, (uint32_t)s_base);
                 published = true;
