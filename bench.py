@@ -65,8 +65,14 @@ def parse_args(argv=None):
                     help="model: the SURVEY 8(d) value model (default, the headline workload).  noise: iid U[0, 2^30) cells -- the "
                          "adversarial set of SURVEY 8(d): every instant's Snapshot wins chunk.rs:62, i.e. the general (re-reading) "
                          "emission path and one-instant blocks; a throughput figure for that path, never the headline")
-    ap.add_argument("--host-sample", type=int, default=48, help="chunks pushed through the host-buffer entry point for the "
-                    "PCIe-inclusive end-to-end figure (0 = skip)")
+    ap.add_argument("--host-sample", type=int, default=1024, help="chunks pushed through the host-buffer entry point for the "
+                    "PCIe-inclusive end-to-end figure (0 = skip); 1024 chunks = 8.6 GB of int32 input: long enough for the pinned "
+                    "double buffers of the upload and of the download to reach their steady state")
+    ap.add_argument("--decode-queries", type=int, default=200000,
+                    help="after the timed region (full configs[2] int32 raster, N = 1 only): this many configs[4] queries against the "
+                         "chunks the session left on the device -> the line's \"decode\" object (0 = skip)")
+    ap.add_argument("--also", default="i64,f32", help="after the timed region (full configs[2] int32 raster, N = 1 only): short runs "
+                    "of the same raster in these element types -> the line's \"also\" object ('' = skip)")
     return ap.parse_args(argv)
 
 
@@ -236,6 +242,8 @@ def main():
             data = [data[0]] * len(data)
         torch.cuda.synchronize()
         workload += "; DCDF_BENCH_SAME=" + same
+    full_config2 = (args.workload == "config2" and args.dtype == "i32" and args.dataset == "model" and args.days == 365 and
+                    args.extent == 4096 and not same)
     descs = [(d.data_ptr(), code, (S * S, S, 1), tuple(d.shape), fb, 0) for d in data]
     enc = Encoder(descs, k=2)
     cells_local = sum(d.numel() for d in data)
@@ -320,13 +328,21 @@ def main():
             gather = {"device_pack_and_d2h_s": g1 - g0, "rank_exchange_s": g2 - g1, "chunks": nchunks, "bytes": total_b,
                       "minmax_pairs": total_mm, "sha256_of_concatenation_in_chunk_order": sha,
                       "note": "host-side, after the timed region; equal sha256 for every --gpus N of one workload"}
+            # the golden of tests/test_gpu_configs.py (every one of the 3072 chunks compared with the oracle there)
+            if full_config2:
+                try:
+                    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config2_sha256.json")))
+                    gather["sha_matches_golden"] = sha == gold["sha256_of_concatenation_in_chunk_order"]
+                except Exception:
+                    gather["sha_matches_golden"] = None
 
     # ---- untimed parity spot check against the oracle (rank 0) -------------------------------------
     verified = 0
     cpu = None
     if rank == 0:
         import oracle_lib as O
-        for c in range(min(args.verify, n)):
+        nv = min(args.verify, n)
+        for c in sorted(set(int(round(i * (n - 1) / max(1, nv - 1))) for i in range(nv))) if nv else []:  # spread over all time segments
             host = data[c].cpu().numpy()
             assert enc.fetch(c) == O.chunk_build(host, fractional_bits=fb), "chunk %d: encoded bytes differ from the oracle" % c
             verified += 1
@@ -368,18 +384,21 @@ def main():
         hd = (L.TileDesc * len(hs))()
         for i, a in enumerate(hs):
             hd[i] = _desc(a, fb, False)
-        best = None
+        best, out_b = None, 0
         for _ in range(3):
             res = C.POINTER(L.Encoded)()
             h0 = time.perf_counter()
             L.check(L.lib().dcdf_chunk_build_batch(hd, C.c_size_t(len(hs)), 2, L.MEM_HOST, C.byref(res)), "chunk_build_batch")
             dt = time.perf_counter() - h0
+            out_b = sum(int(res[i].len) for i in range(len(hs)))
             L.lib().dcdf_free_encoded(res, C.c_size_t(len(hs)))
             best = dt if best is None else min(best, dt)
         hcells = sum(a.size for a in hs)
         end_to_end = {"entry": "dcdf_chunk_build_batch, tiles and results in host memory (staging + H2D + kernel + D2H)",
                       "value": hcells / best, "unit": "cells/s", "input_GB_per_s": hcells * esz / best / 1e9,
-                      "sample": "first %d chunks of this workload, best of 3 (%.3f s)" % (len(hs), best)}
+                      "output_GB_per_s": out_b / best / 1e9, "input_bytes": hcells * esz, "output_bytes": out_b,
+                      "sample": "first %d chunks of this workload, pageable numpy arrays in, malloc'ed buffers out, best of 3 (%.3f s)" % (len(hs), best)}
+        del hs, hd
 
     # ---- "also report against a measured device-to-device copy on the same GPU" ------------------------------
     copy_gbs = None
@@ -396,6 +415,52 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 5 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9  # bytes read + bytes written
         del a, b
+
+    # ---- BASELINE configs[4] (row d2): a bounded sample of the decode path against the chunks this session left on the device ----
+    decode = None
+    if rank == 0 and world == 1 and full_config2 and args.decode_queries > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_query
+        d0 = time.perf_counter()
+        q = bench_query.run(queries=args.decode_queries, batch=min(args.decode_queries, 100000), check=4, cpu_sample=1500,
+                            host_results=False, session=(enc, args.days))
+        rl, cb = q["roofline"], q.get("cpu_baseline") or {}
+        decode = {"workload": q["config"]["workload"], "queries": args.decode_queries,
+                  "queries_per_s": q["queries_per_s"], "cells_per_s": q["value"],
+                  "kernel_ms": q["fill_window"]["kernel_ms"] + q["search_window"]["kernel_ms"],
+                  "fill_window": {k: q["fill_window"][k] for k in ("queries", "chunk_level_subqueries", "kernel_ms", "cells", "cells_per_s_kernel", "queries_per_s_kernel")},
+                  "search_window": {k: q["search_window"][k] for k in ("queries", "chunk_level_subqueries", "kernel_ms", "hits", "queries_per_s_kernel")},
+                  "answers_checked_vs_model": q["config"]["answers_checked_vs_model"],
+                  "open_chunks_s": q["open"]["seconds"],
+                  "end_to_end_raster_entry_points": q["end_to_end"]["raster_level"],
+                  "roofline": {"bound": "hbm", "achieved": rl["achieved"], "peak": rl["peak"], "unit": "GB/s", "frac": rl["frac"],
+                               "traffic": rl.get("traffic"), "traffic_detail": rl.get("traffic_detail"),
+                               "algorithmic_bytes": rl["fill_window"]["algorithmic_bytes"] + rl["search_window"]["algorithmic_bytes"],
+                               "algorithmic_bytes_upper_bound_whole_structures": rl["fill_window"]["encoded_bytes_upper_bound"] + rl["fill_window"]["output_bytes"] +
+                               rl["search_window"]["encoded_bytes_upper_bound"] + rl["search_window"]["output_bytes"],
+                               "kernel": "k2r::k_window_wave2 (+ k_search_count / k_search_emit)", "note": rl["note"]},
+                  "cpu_baseline": {"kind": cb.get("kind"), "unit": cb.get("unit"), "cores": 1, "sample": cb.get("sample"),
+                                   "fill_window": cb.get("fill_window"), "search_window": cb.get("search_window"),
+                                   "gpu_subqueries_per_s_kernel": cb.get("gpu_subqueries_per_s_kernel")},
+                  "wall_s": time.perf_counter() - d0}
+
+    # ---- the same raster in the other element types: short runs in child processes (this one keeps its memory) ----------------
+    also = None
+    if rank == 0 and world == 1 and full_config2 and args.also:
+        also = {}
+        for dt in [x for x in args.also.split(",") if x and x != "i32"]:
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt, "--steps", "3", "--warmup", "1", "--no-gather", "--cpu-sample", "0",
+                   "--host-sample", "0", "--verify", "2", "--decode-queries", "0", "--also", ""]
+            try:
+                out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True).stdout.decode()
+                cl = json.loads(out.strip().splitlines()[-1])
+                also[cl["dtype"]] = {"value": cl["value"], "unit": cl["unit"], "kernel_ms": cl["roofline"]["kernel_ms"],
+                                     "frac": cl["roofline"]["frac"], "kernel": cl["roofline"]["kernel"],
+                                     "algorithmic_bytes": cl["roofline"]["algorithmic_bytes"], "steps": cl["steps"],
+                                     "failed_tiles": cl["config"]["failed_tiles_rank0"],
+                                     "bytes_verified_vs_oracle": cl["config"]["bytes_verified_vs_oracle"]}
+            except Exception as e:  # (a side figure must never take the headline line down)
+                also[dt] = {"error": repr(e)[:200]}
 
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
@@ -443,6 +508,8 @@ def main():
             "cpu_baseline": cpu,
             "end_to_end_host_buffers": end_to_end,
             "gather": gather,
+            "decode": decode,
+            "also": also,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -77,16 +77,34 @@ def make_queries(rng, n, TT, extent, nt):
     return (t0, t1, r0, r1, c0, c1), sub
 
 
-def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_sample=4000, host_results=True, verbose=False):
+def query_source_sha():
+    """Identifies the decode kernels' sources a committed PMC profile belongs to (roofline.traffic is only quoted for them)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("k2r_common.h", "k2r_decode.h", "k2r_query.hip"):
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "dcdf_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_sample=4000, host_results=True, verbose=False,
+        session=None, raster_level=True):
+    """session = (encoder, instants): query the chunks an existing encoder session (bench.py's, already run) left on the device
+    instead of encoding the raster here; the session stays open."""
     import dcdf_amd as dc
     from dcdf_amd import _lib as L, synth
     from dcdf_amd.encoder import DeviceBuffer
     nt = extent // 256
-    enc, grid, TT, raster = encode_raster(segments, extent)
+    if session is None:
+        enc, grid, TT, raster = encode_raster(segments, extent)
+    else:
+        enc, TT = session
+        raster = None
     t0 = time.perf_counter()
     chunks = enc.open_chunks()  # (returns when the device is done: the call synchronises)
     open_s = time.perf_counter() - t0
-    raster.free()  # the queries run against the encoded chunks alone
+    if raster is not None:
+        raster.free()  # the queries run against the encoded chunks alone
     from dcdf_amd.raster import EncodedRaster
     ER = EncodedRaster((TT, extent, extent), chunks)
     nat_f_wall = nat_s_wall = nat_f_ms = nat_s_ms = 0.0
@@ -173,20 +191,22 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
         dev.free()
         # the same dataset-level cubes through dcdf_raster_fill_window_batch: the split into pieces happens in the library
         w0 = time.perf_counter()
-        dcub = np.ascontiguousarray(np.stack(spec[:6], axis=1).astype(np.uint32))
-        dvol = ((dcub[:, 1].astype(np.int64) - dcub[:, 0]) * (dcub[:, 3].astype(np.int64) - dcub[:, 2]) * (dcub[:, 5].astype(np.int64) - dcub[:, 4]))
-        doff = np.concatenate([[0], np.cumsum(dvol)[:-1]]).astype(np.uint64)
-        assert int(dvol.sum()) == total
-        dev = DeviceBuffer(max(4, total * 4))
-        nat_f_ms += ER.fill_windows_flat(dcub, dtype=np.int32, out_device_ptr=dev.ptr, out_offset=doff)
-        nat_f_wall += time.perf_counter() - w0
-        if check:
+        dcub = np.ascontiguousarray(np.stack(spec[:6], axis=1).astype(np.uint32)) if raster_level else None
+        if raster_level:
+            dvol = ((dcub[:, 1].astype(np.int64) - dcub[:, 0]) * (dcub[:, 3].astype(np.int64) - dcub[:, 2]) * (dcub[:, 5].astype(np.int64) - dcub[:, 4]))
+            doff = np.concatenate([[0], np.cumsum(dvol)[:-1]]).astype(np.uint64)
+            assert int(dvol.sum()) == total
+            dev = DeviceBuffer(max(4, total * 4))
+            nat_f_ms += ER.fill_windows_flat(dcub, dtype=np.int32, out_device_ptr=dev.ptr, out_offset=doff)
+            nat_f_wall += time.perf_counter() - w0
+        if check and raster_level:
             outn = dev.read(0, total * 4, np.int32)
             for q in rng.integers(0, half, check):
                 ref, _ = brute(q, spec)
                 assert (outn[int(doff[q]):int(doff[q]) + ref.size].reshape(ref.shape) == ref).all(), "raster fill_window mismatch"
                 checked += 1
-        dev.free()
+        if raster_level:
+            dev.free()
         # ---- search_window half: [lower, upper] = a random 10-percentile-wide band of the value range ----
         w0 = time.perf_counter()
         spec, sub = make_queries(rng, n - half, TT, extent, nt)
@@ -230,20 +250,22 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
             cpu_s += [tuple(int(x) for x in sub[k, 1:8]) + (int(lower[k]), int(upper[k])) for k in range(min(m, cpu_sample - len(cpu_s)))]
         dtrip.free()
         w0 = time.perf_counter()
-        dcub = np.ascontiguousarray(np.stack(spec[:6], axis=1).astype(np.uint32))
-        dtrip = DeviceBuffer(max(12, total * 12))
-        _, noff, ncnt, ms_n = ER.search_flat(dcub, qlo[:, 0], qlo[:, 1], out_device_ptr=dtrip.ptr, cap=total)
-        nat_s_ms += ms_n
-        nat_s_wall += time.perf_counter() - w0
-        assert int(ncnt.sum()) == int(counts.sum())
-        if check:
+        if raster_level:
+            dcub = np.ascontiguousarray(np.stack(spec[:6], axis=1).astype(np.uint32))
+            dtrip = DeviceBuffer(max(12, total * 12))
+            _, noff, ncnt, ms_n = ER.search_flat(dcub, qlo[:, 0], qlo[:, 1], out_device_ptr=dtrip.ptr, cap=total)
+            nat_s_ms += ms_n
+            nat_s_wall += time.perf_counter() - w0
+            assert int(ncnt.sum()) == int(counts.sum())
+        if check and raster_level:
             trip = dtrip.read(0, int(ncnt.sum()) * 12, np.uint32).reshape(-1, 3).astype(np.int64)
             for q in rng.integers(0, n - half, check):
                 ref, (t0_, r0, c0) = brute(q, spec)
                 want = set(map(tuple, (np.argwhere((ref >= qlo[q, 0]) & (ref <= qlo[q, 1])) + np.array([t0_, r0, c0])).tolist()))
                 assert set(map(tuple, trip[int(noff[q]):int(noff[q]) + int(ncnt[q])].tolist())) == want, "raster search mismatch"
                 checked += 1
-        dtrip.free()
+        if raster_level:
+            dtrip.free()
         if verbose:
             print("batch %d done" % b0, file=sys.stderr)
 
@@ -282,8 +304,8 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
                        "note": "host routing (numpy) + handle arrays + the call; device result: nothing but counts crosses PCIe",
                        "raster_level": {"entry": "dcdf_raster_fill_window_batch / dcdf_raster_search_batch (dataset-level cubes; the split into "
                                                  "chunk-level pieces and the placement of every piece happen in the library)",
-                                        "fill_window_queries_per_s_device_result": nqf / nat_f_wall, "fill_window_kernel_ms": nat_f_ms,
-                                        "search_queries_per_s_device_result": nqs / nat_s_wall, "search_kernel_ms": nat_s_ms}},
+                                        "fill_window_queries_per_s_device_result": nqf / nat_f_wall if nat_f_wall else None, "fill_window_kernel_ms": nat_f_ms,
+                                        "search_queries_per_s_device_result": nqs / nat_s_wall if nat_s_wall else None, "search_kernel_ms": nat_s_ms}},
     }
     # ---- CPU baseline: the oracle's Chunk::fill_window / iter_search on the sampled sub-queries --------------------------------
     if cpu_sample:
@@ -320,10 +342,23 @@ def run(queries=1000000, batch=250000, segments=12, extent=4096, check=20, cpu_s
                               "all_cores": {"cores": nthr, "value": len(cpu_s) * rsn / tsn, "hits_per_s": wsn / tsn, "seconds": tsn}},
             "gpu_subqueries_per_s_kernel": {"fill_window": nsub_f / (fw_ms * 1e-3), "search_window": nsub_s / (se_ms * 1e-3)},
         }
+    # HBM bytes of the decode kernels come from separate rocprofv3 PMC passes of this tool (tools/collect_query_profiles.sh),
+    # quoted only for the same query count and kernel sources
+    tf = os.path.join(ROOT, "profiles", "query_traffic_latest.json")
+    if os.path.exists(tf):
+        try:
+            rec = json.load(open(tf))
+            if rec.get("source_sha") == query_source_sha() and rec.get("queries") == nq:
+                res["roofline"]["traffic"] = rec.get("hbm_bytes_all_query_kernels")
+                res["roofline"]["traffic_detail"] = {k: rec.get(k) for k in ("tag", "fetch_bytes_x2", "write_bytes", "per_kernel")}
+        except Exception:
+            pass
+    res["roofline"]["source_sha"] = query_source_sha()
     ER.close()
     for c in chunks:
         c.close()
-    enc.close()
+    if session is None:
+        enc.close()
     return res
 
 
@@ -334,9 +369,10 @@ def main():
     ap.add_argument("--segments", type=int, default=12, help="time segments of the raster to encode (12 = all 365 instants)")
     ap.add_argument("--cpu-sample", type=int, default=4000)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-raster-level", action="store_true", help="chunk-level entry points only (PMC passes: the kernels are the same)")
     args = ap.parse_args()
     res = run(args.queries, args.batch, args.segments, check=0 if args.no_check or os.environ.get("BENCH_QUERY_NO_CHECK") else 20,
-              cpu_sample=args.cpu_sample, verbose=True)
+              cpu_sample=args.cpu_sample, verbose=True, raster_level=not args.no_raster_level)
     print(json.dumps(res))
 
 
