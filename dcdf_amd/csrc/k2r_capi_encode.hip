@@ -77,7 +77,7 @@ static size_t plan_split(const std::vector<uint32_t>& inst, uint32_t wgs) {
 static std::vector<uint32_t> part_bounds(uint32_t T) {
     std::vector<uint32_t> b;
     const char* env = std::getenv("K2R_PARTS");
-    const uint32_t maxp = env ? (uint32_t)std::max(2, std::min(8, std::atoi(env))) : 4u;
+    const uint32_t maxp = env ? (uint32_t)std::max(2, std::min(8, std::atoi(env))) : 8u;  // (8 parts: 0.934 of linear on the N = 8 share, 4: 0.919; profiles/r04r)
     uint32_t at = 0, left = T;
     while (b.size() + 2 <= maxp && left >= 4) {
         at += (left + 1) / 2;
@@ -93,6 +93,12 @@ static std::vector<uint32_t> part_bounds(uint32_t T) {
 // patched, the counters added.  Otherwise ST_RESPLIT (the host re-encodes the tile whole); an error of any part is the
 // tile's error.
 constexpr int kMaxParts = 8;
+// COPY = false (inside dcdf_encoder_run, timed): the checks, the totals and the two header patches -- the continuations' bytes
+// stay in their own slots.  COPY = true (materialize(), the first time somebody asks for the bytes: gather, download, fetch, the
+// device pointer, hashing): the bytes are appended.  The copy is 250 MB per launch for the N = 8 share of configs[3], 7 % of
+// that launch, and a gather copies every byte again anyway.  TileResult::_pad2 of the first part keeps its own length between
+// the two.
+template <bool COPY>
 __global__ void __launch_bounds__(1024) k_stitch(const uint32_t* __restrict__ first, const uint32_t* __restrict__ items,
                                                   const TileArgs* __restrict__ args, TileResult* __restrict__ res) {
     __shared__ int32_t s_st;
@@ -101,13 +107,13 @@ __global__ void __launch_bounds__(1024) k_stitch(const uint32_t* __restrict__ fi
     const uint32_t a = items[i0];
     if (threadIdx.x == 0) {
         int32_t st = ST_OK;
-        uint64_t total = res[a].len;
+        uint64_t total = COPY ? (uint64_t)res[a]._pad2 : res[a].len;
         if (res[a].status != ST_OK) st = res[a].status;
-        else if (res[a].snapshots != 1) st = ST_RESPLIT;
+        else if (!COPY && res[a].snapshots != 1) st = ST_RESPLIT;
         for (uint32_t p = 1; p < np && st == ST_OK; p++) {
             const uint32_t b = items[i0 + p];
             if (res[b].status != ST_OK) st = res[b].status;
-            else if (p + 1 < np && res[b].snapshots != 0) st = ST_RESPLIT;
+            else if (!COPY && p + 1 < np && res[b].snapshots != 0) st = ST_RESPLIT;
             s_at[p] = total;
             total += res[b].len;
         }
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(1024) k_stitch(const uint32_t* __restrict__ fi
     }
     __syncthreads();
     const int32_t st = s_st;
-    if (st == ST_OK) {
+    if (COPY && st == ST_OK) {
         // 16 bytes per thread and step (a source slot is 256-byte aligned; the destination is wherever the previous part ended:
         // global memory takes unaligned vector stores), then the tail
         typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(1)));
@@ -131,12 +137,12 @@ __global__ void __launch_bounds__(1024) k_stitch(const uint32_t* __restrict__ fi
             for (uint64_t i = 16 * nv + threadIdx.x; i < lb; i += blockDim.x) dst[i] = src[i];
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (!COPY && threadIdx.x == 0) {
         if (st == ST_OK) {
             const uint32_t last = items[i0 + np - 1];
             args[a].out[6] = (uint8_t)res[last].carry_count;
             store_be32(args[a].out + 2, 1u + res[last].snapshots);
+            res[a]._pad2 = (uint32_t)res[a].len;  // (a slot holds far less than 4 GB)
             res[a].len = s_at[np];
             for (uint32_t p = 1; p < np; p++) {
                 const uint32_t b = items[i0 + p];
@@ -177,6 +183,7 @@ struct dcdf_encoder {
     // instants and extra TileArgs at indices >= n for the rest, spliced by k_stitch inside the timed region.
     std::vector<std::vector<uint32_t>> class_items;  // per class: the launch order (tile indices and extra indices >= n)
     std::vector<std::vector<uint32_t>> split;        // per split tile: {tile, continuation items in order}
+    bool spliced = true;                             // false between a run and the first request for a split tile's bytes
     DevBuf d_part_first, d_part_items, d_out_b, d_flags, d_shared;
     // tiles outside the fused kernel's contract (k != 2, sidelen < 8 or > 256): encoded by the universal kernel
     // (k2r_generic.hip); key = k << 8 | H
@@ -423,9 +430,11 @@ static int run_classes(dcdf_encoder* e, const std::vector<std::vector<uint32_t>>
         L.grid = std::min(e->grid[ci], std::max(1u, nt));
         K2R_HIP(launch_encode(e->classes[ci], L, e->stream));
     }
-    if (!subset && !e->split.empty())  // splice the speculative parts (inside the timed region)
-        hipLaunchKernelGGL(k2r::k_stitch, dim3((uint32_t)e->split.size()), dim3(1024), 0, e->stream, e->d_part_first.as<uint32_t>(),
+    if (!subset && !e->split.empty()) {  // check and account the speculative parts (inside the timed region); bytes: materialize()
+        hipLaunchKernelGGL(k2r::k_stitch<false>, dim3((uint32_t)e->split.size()), dim3(1024), 0, e->stream, e->d_part_first.as<uint32_t>(),
                            e->d_part_items.as<uint32_t>(), e->d_args.as<TileArgs>(), e->d_results.as<TileResult>());
+        e->spliced = false;
+    }
     K2R_HIP(hipEventRecord(e->ev1, e->stream));
     K2R_HIP(hipStreamSynchronize(e->stream));
     if (kernel_ms) K2R_HIP(hipEventElapsedTime(kernel_ms, e->ev0, e->ev1));
@@ -662,9 +671,28 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
     return DCDF_OK;
 }
 
+// The bytes of the tiles that were encoded in parts, made contiguous in the first part's slot (k_stitch<true>): once per run,
+// the first time they are asked for.
+static int materialize(dcdf_encoder* e) {
+    if (e->spliced || e->split.empty()) {
+        e->spliced = true;
+        return DCDF_OK;
+    }
+    hipLaunchKernelGGL(k2r::k_stitch<true>, dim3((uint32_t)e->split.size()), dim3(1024), 0, e->stream, e->d_part_first.as<uint32_t>(),
+                       e->d_part_items.as<uint32_t>(), e->d_args.as<TileArgs>(), e->d_results.as<TileResult>());
+    K2R_HIP(hipGetLastError());
+    K2R_HIP(hipStreamSynchronize(e->stream));
+    e->spliced = true;
+    return DCDF_OK;
+}
+
 extern "C" int dcdf_encoder_result(dcdf_encoder* e, size_t i, int32_t* status, uint64_t* len, uint32_t* snapshots,
                                    uint32_t* logs, const uint8_t** device_bytes) {
     if (!e || i >= e->desc.size()) return DCDF_ERR_BAD_ARG;
+    if (device_bytes) {
+        const int mrc = materialize(e);
+        if (mrc != DCDF_OK) return mrc;
+    }
     const bool pre_ok = e->pre_status[i] == DCDF_OK;
     const TileResult& r = e->results[i];
     const int st = pre_ok ? map_status(r.status) : e->pre_status[i];
@@ -682,6 +710,10 @@ extern "C" int dcdf_encoder_fetch(dcdf_encoder* e, size_t i, uint8_t* dst, size_
     const TileResult& r = e->results[i];
     if (r.status != ST_OK) return map_status(r.status);
     if (cap < r.len) return DCDF_ERR_CAPACITY;
+    {
+        const int mrc = materialize(e);
+        if (mrc != DCDF_OK) return mrc;
+    }
     K2R_HIP(hipMemcpy(dst, e->args[i].out, r.len, hipMemcpyDeviceToHost));
     return DCDF_OK;
 }
@@ -692,6 +724,10 @@ hipError_t launch_object_sha256(const TileArgs* tiles, const TileResult* results
 
 extern "C" int dcdf_encoder_object_sha256(dcdf_encoder* e, uint8_t* digests, float* kernel_ms) {
     if (!e || !digests) return DCDF_ERR_BAD_ARG;
+    {
+        const int mrc = materialize(e);
+        if (mrc != DCDF_OK) return mrc;
+    }
     const size_t n = e->desc.size();
     // the statuses the kernel may trust: tiles rejected on the host never reached the device
     std::vector<TileResult> res(e->results);
@@ -745,6 +781,10 @@ extern "C" int dcdf_encoder_gather_size(dcdf_encoder* e, uint64_t* packed_bytes,
 
 extern "C" int dcdf_encoder_gather(dcdf_encoder* e, uint8_t* dst, size_t cap, uint64_t* offsets, uint64_t* lens, int64_t* minmax) {
     if (!e || !dst || !offsets || !lens) return DCDF_ERR_BAD_ARG;
+    {
+        const int mrc = materialize(e);
+        if (mrc != DCDF_OK) return mrc;
+    }
     const size_t n = e->desc.size();
     std::vector<PackItem> items;
     uint64_t tot = 0;
@@ -994,6 +1034,10 @@ namespace k2r {
 void host_parallel_for(size_t n, const std::function<void(size_t)>& f) { parallel_for(n, f); }
 
 int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst) {
+    {
+        const int mrc = materialize(e);
+        if (mrc != DCDF_OK) return mrc;
+    }
     const size_t n = e->desc.size();
     std::vector<uint64_t> lens(n, 0);
     for (size_t i = 0; i < n; i++)
