@@ -1033,7 +1033,7 @@ static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dc
 namespace k2r {
 void host_parallel_for(size_t n, const std::function<void(size_t)>& f) { parallel_for(n, f); }
 
-int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst) {
+int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst, const std::function<void(size_t)>& landed) {
     {
         const int mrc = materialize(e);
         if (mrc != DCDF_OK) return mrc;
@@ -1058,7 +1058,10 @@ int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint6
             const size_t ti = pend[b][q];
             uint8_t* d = dst(ti, lens[ti]);
             if (!d) bad = true;
-            else std::memcpy(d, pb + pend_off[b][q], lens[ti]);
+            else {
+                std::memcpy(d, pb + pend_off[b][q], lens[ti]);
+                if (landed) landed(ti);
+            }
         });
         pend[b].clear();
         pend_off[b].clear();
@@ -1085,6 +1088,7 @@ int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint6
             uint8_t* d = dst(i, lens[i]);
             if (!d) return quiesce(DCDF_ERR_NOMEM);
             K2R_HIP_Q(hipMemcpy(d, e->args[i].out, lens[i], hipMemcpyDeviceToHost));
+            if (landed) landed(i);
             i++;
             continue;
         }

@@ -1401,8 +1401,10 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 const uint32_t ltid = opaque((uint32_t)tid), lane = ltid & 63u, j = lane & 3u;
                 int32_t err = 0;
                 // (the next pass's cells are requested before this pass's are analysed: K2R_LEAN_PREFETCH)
+#ifdef K2R_LEAN_PREFETCH
                 int32_t tn[16];
                 uint32_t wn[8];
+#endif
                 auto request = [&](int p, int32_t (&tt)[16], uint32_t (&ww)[8]) {
                     const uint32_t Bp = (ltid & ~63u) + BPP * (uint32_t)p + (lane >> 2);
                     uint32_t br, bc;

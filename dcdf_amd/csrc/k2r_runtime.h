@@ -183,7 +183,9 @@ struct dcdf_encoder;
 namespace k2r {
 // The encoded bytes of a finished session, device slots -> pinned double buffer -> wherever `dst(tile, len)` says (called once
 // per tile with bytes, from worker threads; it may allocate the destination there).  k2r_capi_encode.hip.
-int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst);
+// `landed(tile)`, if given, runs on the worker thread right after a tile's bytes have been copied to their destination.
+int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst,
+                     const std::function<void(size_t)>& landed = nullptr);
 // runs f(0..n) on a few host threads
 void host_parallel_for(size_t n, const std::function<void(size_t)>& f);
 

@@ -14,7 +14,10 @@
 //   * per-tile fractional bits (superchunk.rs:167): dcdf_suggest_fraction (device reductions, k2r_suggest.hip);
 //   * Chunk::build of every non-elided bottom tile: ONE batched launch of the encoder (dcdf_chunk_build_batch);
 //   * the instant-major min / max Dacs (superchunk.rs:190-198,246-247): `k_dac_pack` (k2r_generic.hip);
-//   * SHA-256 of every stored object: `k_sha256_buffers` (k2r_cid.hip).
+//   * SHA-256 of every stored object: on the host (x86 SHA extensions, k2r_sha256_host.h) by the download's worker threads as each
+//     object lands in host memory -- a hash is one serial chain per object, 139 ms on one GPU lane for the 1.4 MB sub-chunks of a
+//     4096^2 level against 15 ms overlapped with the copy; the device kernels (`k_object_sha256`, `k_sha256_buffers`, k2r_cid.hip)
+//     remain for objects that stay in HBM (dcdf_encoder_object_sha256).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -32,6 +35,7 @@
 
 #include "k2r_encode.h"
 #include "k2r_runtime.h"
+#include "k2r_sha256_host.h"
 
 namespace k2r {
 hipError_t launch_dac_pack(const int64_t* values, uint64_t n, uint8_t* out, uint8_t* tmp, uint64_t* out_len, hipStream_t stream);
@@ -128,12 +132,34 @@ struct Level {
     uint64_t size_self = 0, size = 0;
     uint32_t elided = 0, external = 0, snapshots = 0, logs = 0;
 };
+struct Blob {  // a stored object in malloc'ed memory (handed to the caller as it is: no copy at the end)
+    uint8_t* p = nullptr;
+    size_t n = 0;
+};
+Blob blob_of(const std::string& s) {
+    Blob b;
+    b.p = (uint8_t*)std::malloc(s.size() ? s.size() : 1);
+    b.n = s.size();
+    if (b.p) std::memcpy(b.p, s.data(), s.size());
+    return b;
+}
 struct Ctx {
     int k;
-    std::vector<std::string> objects;            // in save order, de-duplicated
+    std::vector<Blob> objects;                   // in save order, de-duplicated
     std::map<std::string, size_t> by_cid;        // cid -> index in objects
     std::vector<std::string> cids;
+    bool nomem = false;
+    ~Ctx() {
+        for (Blob& b : objects) std::free(b.p);  // (released objects are nulled)
+    }
 };
+std::string cid_of(const uint8_t* p, size_t n) {  // testing.rs:172-183: CIDv1, codec 0x12, sha2-256
+    uint8_t d[32];
+    sha256_host(p, n, d);
+    std::string c("\x01\x12\x12\x20", 4);
+    c.append((const char*)d, 32);
+    return c;
+}
 
 void put_u32(std::string& s, uint32_t v) {
     const char b[4] = {(char)(v >> 24), (char)(v >> 16), (char)(v >> 8), (char)v};
@@ -149,42 +175,21 @@ std::string header(uint8_t node_type) {  // resolver.rs:130-133
 }
 size_t esize(int dtype) { return (dtype == DCDF_I32 || dtype == DCDF_F32) ? 4 : 8; }
 
-// CIDs of a batch of objects: SHA-256 on the device (testing.rs:172-183)
+// CIDs of a batch of small host-resident objects (nested Superchunk nodes, Links)
 int hash_objects(const std::vector<const std::string*>& objs, std::vector<std::string>& cids) {
     cids.clear();
-    if (objs.empty()) return DCDF_OK;
-    std::vector<uint64_t> offs, lens;
-    uint64_t total = 0;
-    for (auto* o : objs) {
-        offs.push_back(total);
-        lens.push_back(o->size());
-        total += (o->size() + 7) & ~7ull;
-    }
-    std::vector<uint8_t> flat(total ? total : 8, 0);
-    for (size_t i = 0; i < objs.size(); i++) std::memcpy(flat.data() + offs[i], objs[i]->data(), objs[i]->size());
-    DevBuf d_data, d_offs, d_lens, d_dig;
-    K2R_HIP(d_data.alloc(flat.size()));
-    K2R_HIP(d_offs.alloc(objs.size() * 8));
-    K2R_HIP(d_lens.alloc(objs.size() * 8));
-    K2R_HIP(d_dig.alloc(objs.size() * 32));
-    K2R_HIP(hipMemcpy(d_data.p, flat.data(), flat.size(), hipMemcpyHostToDevice));
-    K2R_HIP(hipMemcpy(d_offs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice));
-    K2R_HIP(hipMemcpy(d_lens.p, lens.data(), lens.size() * 8, hipMemcpyHostToDevice));
-    K2R_HIP(launch_sha256_buffers(d_data.as<uint8_t>(), d_offs.as<uint64_t>(), d_lens.as<uint64_t>(), (uint32_t)objs.size(), d_dig.as<uint8_t>(), 0));
-    std::vector<uint8_t> dig(objs.size() * 32);
-    K2R_HIP(hipMemcpy(dig.data(), d_dig.p, dig.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < objs.size(); i++) {
-        std::string c("\x01\x12\x12\x20", 4);
-        c.append((const char*)dig.data() + 32 * i, 32);
-        cids.push_back(c);
-    }
+    for (auto* o : objs) cids.push_back(cid_of((const uint8_t*)o->data(), o->size()));
     return DCDF_OK;
 }
 // resolver.save: remember the object under its CID (content addressing makes identical objects one object)
-void save(Ctx& cx, const std::string& cid, std::string obj) {
-    if (cx.by_cid.count(cid)) return;
+void save(Ctx& cx, const std::string& cid, Blob obj) {  // (takes ownership)
+    if (!obj.p) cx.nomem = true;
+    if (cx.by_cid.count(cid) || !obj.p) {
+        std::free(obj.p);
+        return;
+    }
     cx.by_cid[cid] = cx.objects.size();
-    cx.objects.push_back(std::move(obj));
+    cx.objects.push_back(obj);
     cx.cids.push_back(cid);
 }
 // Dac::from(values).write_to on the device
@@ -285,11 +290,19 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
     struct Sub {
         size_t tile;
         bool chunk;
-        std::string obj;
+        std::string obj;   // a nested Superchunk node
+        Blob blob;         // a framed sub-chunk, filled by the download
         uint64_t size;
         uint32_t snapshots, logs;
     };
+    struct SubsGuard {  // (blobs not handed over to the context yet)
+        std::vector<Sub>& v;
+        ~SubsGuard() {
+            for (Sub& s : v) std::free(s.blob.p);
+        }
+    };
     std::vector<Sub> subs;
+    SubsGuard subs_guard{subs};
     std::vector<dcdf_tile_desc> chunk_descs;
     std::vector<size_t> chunk_sub;
     auto can_elide_tile = [&](size_t i) {
@@ -374,28 +387,26 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             if (rc != DCDF_OK) return rc;
             if (st != DCDF_OK) return st;
         }
-        // SHA-256 of a 1.4 MB object is one serial chain on one lane (≈ 140 ms for the 256 objects of a 4096^2 level): it runs on
-        // the session's stream from a helper thread while this thread gathers the bytes (own stream) and frames the objects
-        std::vector<uint8_t> dig(nc * 32);
-        int sha_rc = DCDF_OK;
-        std::thread sha([&] { sha_rc = dcdf_encoder_object_sha256(g.e, dig.data(), nullptr); });
-        struct Join {
-            std::thread& t;
-            ~Join() {
-                if (t.joinable()) t.join();
-            }
-        } join{sha};
         // the bytes come to the host through the pinned double buffer and land, framed, in their final objects: header + tag
-        // written, then the chunk bytes copied in by the download's worker threads (no intermediate host copy)
+        // written, then the chunk bytes copied in by the download's worker threads, which hash the object there and then
+        // (its CID: SHA-256 on the host while the next buffer is in flight -- k2r_sha256_host.h)
         const std::string hd = header(2) + std::string(1, (char)4);  // NODE_MMSTRUCT3, NODE_SUBCHUNK (mmstruct.rs:215-218)
-        rc = k2r::encoder_download(g.e, [&](size_t q, uint64_t len) {
-            std::string& o = subs[chunk_sub[q]].obj;
-            o.assign(hd);
-            o.resize(hd.size() + len);
-            return (uint8_t*)&o[hd.size()];
-        });
+        rc = k2r::encoder_download(
+            g.e,
+            [&](size_t q, uint64_t len) -> uint8_t* {
+                Blob& o = subs[chunk_sub[q]].blob;
+                o.n = hd.size() + len;
+                o.p = (uint8_t*)std::malloc(o.n);
+                if (!o.p) return nullptr;
+                std::memcpy(o.p, hd.data(), hd.size());
+                return o.p + hd.size();
+            },
+            [&](size_t q) {
+                const Blob& o = subs[chunk_sub[q]].blob;
+                chunk_cid[chunk_sub[q]] = cid_of(o.p, o.n);
+            });
         if (rc != DCDF_OK) return rc;
-        tm.lap("gather");
+        tm.lap("download + framing + sha256");
         for (size_t q = 0; q < nc; q++) {
             uint64_t len = 0;
             uint32_t ns = 0, nl = 0;
@@ -406,12 +417,6 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             s.snapshots = ns;
             s.logs = nl;
         }
-        tm.lap("framing");
-        sha.join();
-        if (sha_rc != DCDF_OK) return sha_rc;
-        for (size_t q = 0; q < nc; q++)
-            chunk_cid[chunk_sub[q]] = std::string("\x01\x12\x12\x20", 4) + std::string((const char*)dig.data() + 32 * q, 32);
-        tm.lap("object sha256 (rest)");
     }
     // ---- instant-major min / max (superchunk.rs:190-198) ----
     std::vector<int64_t> mins(n_tiles * (size_t)instants), maxs(n_tiles * (size_t)instants);
@@ -448,7 +453,12 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
         const std::string& cid = cids[si];
         si++;
         sizes += s.size;
-        save(cx, cid, std::move(s.obj));
+        if (s.chunk) {
+            save(cx, cid, s.blob);
+            s.blob = Blob{};
+        } else {
+            save(cx, cid, blob_of(s.obj));
+        }
         auto it = ext_index.find(cid);
         uint32_t index;
         if (it == ext_index.end()) {
@@ -470,7 +480,7 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
     std::vector<std::string> lcid;
     rc = hash_objects({&links}, lcid);
     if (rc != DCDF_OK) return rc;
-    save(cx, lcid[0], links);
+    save(cx, lcid[0], blob_of(links));
     // ---- the node (superchunk.rs:672-706) ----
     std::string body;
     put_u32(body, instants);
@@ -578,22 +588,26 @@ extern "C" int dcdf_superchunk_build(const dcdf_tile_desc* buffer, const uint32_
         std::free(s);
         return DCDF_ERR_NOMEM;
     }
-    std::atomic<bool> nomem{false};
-    k2r::host_parallel_for(s->n_objects, [&](size_t i) {  // (hundreds of megabytes: a few threads)
-        const std::string& o = i + 1 < s->n_objects ? cx.objects[i] : top.node;
-        const std::string& c = i + 1 < s->n_objects ? cx.cids[i] : tcid[0];
-        s->objects[i].bytes = (uint8_t*)std::malloc(o.size() ? o.size() : 1);
-        if (!s->objects[i].bytes) {
-            nomem = true;
-            return;
-        }
-        std::memcpy(s->objects[i].bytes, o.data(), o.size());
-        s->objects[i].len = o.size();
-        std::memcpy(s->objects[i].cid, c.data(), 36);
-    });
-    if (nomem) {
-        dcdf_free_superchunk(s);
+    if (cx.nomem) {
+        std::free(s->objects);
+        std::free(s);
         return DCDF_ERR_NOMEM;
+    }
+    for (size_t i = 0; i + 1 < s->n_objects; i++) {  // the objects change hands as they are (no copy)
+        s->objects[i].bytes = cx.objects[i].p;
+        s->objects[i].len = cx.objects[i].n;
+        std::memcpy(s->objects[i].cid, cx.cids[i].data(), 36);
+        cx.objects[i].p = nullptr;
+    }
+    {
+        const Blob t = blob_of(top.node);
+        if (!t.p) {
+            dcdf_free_superchunk(s);
+            return DCDF_ERR_NOMEM;
+        }
+        s->objects[s->n_objects - 1].bytes = t.p;
+        s->objects[s->n_objects - 1].len = t.n;
+        std::memcpy(s->objects[s->n_objects - 1].cid, tcid[0].data(), 36);
     }
     s->size = top.size;
     s->elided = top.elided;

@@ -28,14 +28,32 @@ class Superchunk:
         out = C.POINTER(L.SuperchunkBuild)()
         L.check(L.lib().dcdf_superchunk_build(C.byref(d), lv, C.c_size_t(len(levels)), int(k), L.MEM_HOST, C.byref(out)),
                 "Superchunk::build")
-        try:
-            s = out.contents
-            objects = {}
-            cid = None
-            for i in range(s.n_objects):
-                o = s.objects[i]
-                cid = bytes(o.cid)
+        owner = _Owner(out)  # frees the C result when the last view of it is gone
+        s = out.contents
+        objects = {}
+        cid = None
+        for i in range(s.n_objects):
+            o = s.objects[i]
+            cid = bytes(o.cid)
+            if o.len < _VIEW_FROM:
                 objects[cid] = C.string_at(o.bytes, o.len)
-            return SuperchunkBuild(objects, cid, s.size, s.elided, s.local, s.external, s.snapshots, s.logs)
-        finally:
-            L.lib().dcdf_free_superchunk(out)
+            else:
+                # the sub-chunk objects are the bulk (hundreds of MB per slice): read-only views of the library's buffers, no copy
+                arr = (C.c_uint8 * o.len).from_address(C.addressof(o.bytes.contents))
+                arr._owner = owner
+                objects[cid] = memoryview(arr).cast("B").toreadonly()
+        return SuperchunkBuild(objects, cid, s.size, s.elided, s.local, s.external, s.snapshots, s.logs)
+
+
+_VIEW_FROM = 1 << 16
+
+
+class _Owner:
+    def __init__(self, out):
+        self._out = out
+
+    def __del__(self):
+        try:
+            L.lib().dcdf_free_superchunk(self._out)
+        except Exception:
+            pass
