@@ -184,6 +184,9 @@ struct dcdf_encoder {
     std::vector<std::vector<uint32_t>> class_items;  // per class: the launch order (tile indices and extra indices >= n)
     std::vector<std::vector<uint32_t>> split;        // per split tile: {tile, continuation items in order}
     bool spliced = true;                             // false between a run and the first request for a split tile's bytes
+    std::vector<uint32_t> splice_first, splice_items;  // the split tiles whose parts checked out in the last run (k_stitch<false>):
+                                                       // only those are appended by materialize() -- a tile that was re-encoded
+                                                       // whole afterwards (retry, universal kernel) already has all its bytes
     DevBuf d_part_first, d_part_items, d_out_b, d_flags, d_shared;
     // tiles outside the fused kernel's contract (k != 2, sidelen < 8 or > 256): encoded by the universal kernel
     // (k2r_generic.hip); key = k << 8 | H
@@ -497,6 +500,13 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
     int rc = run_classes(e, nullptr, kernel_ms);
     if (rc != DCDF_OK) return rc;
     K2R_HIP(hipMemcpy(e->results.data(), e->d_results.p, n * sizeof(TileResult), hipMemcpyDeviceToHost));
+    e->splice_first.assign(1, 0u);
+    e->splice_items.clear();
+    for (const auto& parts : e->split)
+        if (e->results[parts[0]].status == ST_OK) {
+            for (uint32_t it : parts) e->splice_items.push_back(it);
+            e->splice_first.push_back((uint32_t)e->splice_items.size());
+        }
     if (std::getenv("K2R_PROFILE_PRINT")) {
         uint64_t acc[NPROF] = {0};
         for (size_t i = 0; i < n; i++)
@@ -674,12 +684,17 @@ extern "C" int dcdf_encoder_run(dcdf_encoder* e, float* kernel_ms) {
 // The bytes of the tiles that were encoded in parts, made contiguous in the first part's slot (k_stitch<true>): once per run,
 // the first time they are asked for.
 static int materialize(dcdf_encoder* e) {
-    if (e->spliced || e->split.empty()) {
+    if (e->spliced || e->splice_items.empty()) {
         e->spliced = true;
         return DCDF_OK;
     }
-    hipLaunchKernelGGL(k2r::k_stitch<true>, dim3((uint32_t)e->split.size()), dim3(1024), 0, e->stream, e->d_part_first.as<uint32_t>(),
-                       e->d_part_items.as<uint32_t>(), e->d_args.as<TileArgs>(), e->d_results.as<TileResult>());
+    DevBuf d_first, d_items;
+    K2R_HIP(d_first.alloc(e->splice_first.size() * 4));
+    K2R_HIP(d_items.alloc(e->splice_items.size() * 4));
+    K2R_HIP(hipMemcpyAsync(d_first.p, e->splice_first.data(), e->splice_first.size() * 4, hipMemcpyHostToDevice, e->stream));
+    K2R_HIP(hipMemcpyAsync(d_items.p, e->splice_items.data(), e->splice_items.size() * 4, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k2r::k_stitch<true>, dim3((uint32_t)e->splice_first.size() - 1), dim3(1024), 0, e->stream, d_first.as<uint32_t>(),
+                       d_items.as<uint32_t>(), e->d_args.as<TileArgs>(), e->d_results.as<TileResult>());
     K2R_HIP(hipGetLastError());
     K2R_HIP(hipStreamSynchronize(e->stream));
     e->spliced = true;

@@ -217,6 +217,24 @@ K2R_HD int32_t narrow(int64_t v, int32_t& err) {
 // Four float32 cells -> stored values (VEC == 2).  Fast path: a cell that is NaN, or whose scaled value is an
 // integer below 2^29 in magnitude, converts with a handful of VALU ops; anything else (fractions, huge values,
 // infinities, rounding requested) goes through to_fixed_dev, which reproduces fixed.rs:31-71 and its error kinds.
+// (the exact conversion, out of line on the GPU: inlined at every use -- 16 per sub-block, 64 per thread and phase -- its int64
+// arithmetic made the float kernels four times the size of the integer ones, 53 KB of code for phase 1 alone against a 64 KB
+// instruction cache, for a path the benchmark's exact values never take; returns value | error << 32)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define K2R_OUTLINE __attribute__((noinline))
+#else
+#define K2R_OUTLINE
+#endif
+template <class F>
+K2R_OUTLINE
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t to_fixed_slow(F f, uint32_t fbits, uint32_t round) {
+    int32_t err = 0;
+    const int32_t v = narrow(to_fixed_dev<F>(f, fbits, round != 0, err), err);
+    return (uint64_t)(uint32_t)v | ((uint64_t)(uint32_t)err << 32);
+}
 K2R_HD void fixed4_f32(const float (&f)[4], const TileArgs& ta, float scale, int32_t (&v)[4], int32_t& err) {
     bool all = ta.round == 0;
 #pragma unroll
@@ -229,7 +247,12 @@ K2R_HD void fixed4_f32(const float (&f)[4], const TileArgs& ta, float scale, int
     }
     if (!all) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = narrow(to_fixed_dev<float>(f[i], ta.fbits, ta.round != 0, err), err);
+        for (int i = 0; i < 4; i++) {
+            const uint64_t r = to_fixed_slow<float>(f[i], ta.fbits, ta.round);
+            v[i] = (int32_t)(uint32_t)r;
+            const int32_t re = (int32_t)(uint32_t)(r >> 32);
+            if (re == ST_NONFINITE || (re != 0 && err == 0)) err = re;  // (to_fixed_dev: the first error stays, non-finite overrides)
+        }
     }
 }
 // the same for float64 cells (VEC == 4)
@@ -245,7 +268,12 @@ K2R_HD void fixed4_f64(const double (&f)[4], const TileArgs& ta, double scale, i
     }
     if (!all) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = narrow(to_fixed_dev<double>(f[i], ta.fbits, ta.round != 0, err), err);
+        for (int i = 0; i < 4; i++) {
+            const uint64_t r = to_fixed_slow<double>(f[i], ta.fbits, ta.round);
+            v[i] = (int32_t)(uint32_t)r;
+            const int32_t re = (int32_t)(uint32_t)(r >> 32);
+            if (re == ST_NONFINITE || (re != 0 && err == 0)) err = re;  // (to_fixed_dev: the first error stays, non-finite overrides)
+        }
     }
 }
 K2R_HD double as_f64(int64_t x) {
@@ -1400,12 +1428,9 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                 constexpr uint32_t NTW = NT < 64 ? NT : 64, BPP = NTW / 4;  // lanes per wave, blocks per pass and wave
                 const uint32_t ltid = opaque((uint32_t)tid), lane = ltid & 63u, j = lane & 3u;
                 int32_t err = 0;
-                // (the next pass's cells are requested before this pass's are analysed: K2R_LEAN_PREFETCH)
-#ifdef K2R_LEAN_PREFETCH
-                int32_t tn[16];
-                uint32_t wn[8];
-#endif
-                auto request = [&](int p, int32_t (&tt)[16], uint32_t (&ww)[8]) {
+                // -DK2R_LEAN_PREFETCH=1: the next pass's cells AND copy are requested before this pass's are analysed; =2: the cells
+                // only (16 instead of 24 registers in flight across the analysis; the copy is an L2 hit, the cells come from HBM)
+                auto request_t = [&](int p, int32_t (&tt)[16]) {
                     const uint32_t Bp = (ltid & ~63u) + BPP * (uint32_t)p + (lane >> 2);
                     uint32_t br, bc;
                     morton_decode(4u * Bp + j, br, bc);
@@ -1413,15 +1438,22 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     // (settled here: left symbolic, the range / conversion checks of all four passes are evaluated at the end of
                     // the phase, with every raw cell they look at kept alive -- spilled -- until then)
                     if (VEC >= 2) err = (int32_t)opaque((uint32_t)err);
+                };
+                auto request_w = [&](int p, uint32_t (&ww)[8]) {
+                    const uint32_t Bp = (ltid & ~63u) + BPP * (uint32_t)p + (lane >> 2);
 #ifdef K2R_REGCOPY
 #pragma unroll
                     for (int i = 0; i < 8; i++) ww[i] = r.cw[8 * p + i];
+                    (void)Bp;
 #else
                     load_compact_raw<C>(cmp, (int)Bp, (int)j, ww);
 #endif
                 };
 #ifdef K2R_LEAN_PREFETCH
-                request(0, tn, wn);
+                int32_t tn[16];
+                uint32_t wn[8];
+                request_t(0, tn);
+                if (K2R_LEAN_PREFETCH == 1) request_w(0, wn);
 #endif
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -1430,14 +1462,21 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     int32_t t[16];
                     uint32_t w[8];
 #ifdef K2R_LEAN_PREFETCH
+                    if (K2R_LEAN_PREFETCH != 1) request_w(p, w);
 #pragma unroll
                     for (int i = 0; i < 16; i++) t[i] = tn[i];
+                    if (K2R_LEAN_PREFETCH == 1) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) w[i] = wn[i];
-                    if (p < 3) request(p + 1, tn, wn);
+                        for (int i = 0; i < 8; i++) w[i] = wn[i];
+                    }
+                    if (p < 3) {
+                        request_t(p + 1, tn);
+                        if (K2R_LEAN_PREFETCH == 1) request_w(p + 1, wn);
+                    }
                     sched_fence();
 #else
-                    request(p, t, w);
+                    request_t(p, t);
+                    request_w(p, w);
 #endif
                     LeanSub o;
                     lean_analyse(t, w, o);
@@ -1687,65 +1726,132 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
         const uint32_t rec_corr = lean ? (uint32_t)s_base & 0xffffu : 0u;
         auto rec16 = [&](uint32_t half) -> int32_t { return (int32_t)(int16_t)(uint16_t)(half - rec_corr); };
         auto lng = [](int32_t v) -> uint32_t { return ((uint32_t)v + 128u) > 255u ? 1u : 0u; };  // zig-zag(v) > 0xff
-        if (have_s) {
-            // records that overflowed to global scratch are read by other threads: their stores must have landed
-            if (rec_ovf) ex.barrier_global();
-            if (!(K2R_DIAG_SKIP & 64)) ex.par_nosync([&](int tid, EncRegs&) {
-                for (uint32_t m = (uint32_t)tid; m < stQ; m += NT) {
-                    uint32_t q[3];
-                    if (m < (uint32_t)SH::CAPQ_REC) {
+        // one node of the tree top from its four children (snapshot.rs:476-497, log.rs:776-806)
+        auto top_node = [&](int h, int j) {
+            const int c = C::top_off(h - 1) + 4 * j, a = C::top_off(h) + j;
+            sh.tmin[a] = min4(sh.tmin[c], sh.tmin[c + 1], sh.tmin[c + 2], sh.tmin[c + 3]);
+            sh.tmax[a] = max4(sh.tmax[c], sh.tmax[c + 1], sh.tmax[c + 2], sh.tmax[c + 3]);
+            if (have_s) {
+                sh.smin[a] = min4(sh.smin[c], sh.smin[c + 1], sh.smin[c + 2], sh.smin[c + 3]);
+                sh.smax[a] = max4(sh.smax[c], sh.smax[c + 1], sh.smax[c + 2], sh.smax[c + 3]);
+                const int32_t d0 = sh.diff[c];
+                sh.diff[a] = d0;
+                sh.eq[a] = (sh.eq[c] & sh.eq[c + 1] & sh.eq[c + 2] & sh.eq[c + 3]) && d0 == sh.diff[c + 1] && d0 == sh.diff[c + 2] &&
+                                   d0 == sh.diff[c + 3]
+                               ? 1u
+                               : 0u;
+            }
+        };
+        // the pre-pass over the records first + first + step, first + 2 step, ...
+        auto prepass = [&](uint32_t first, uint32_t step) {
+            for (uint32_t m = first; m < stQ; m += step) {
+                uint32_t q[3];
+                if (m < (uint32_t)SH::CAPQ_REC) {
 #pragma unroll
-                        for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::QBASE + 3u * m + i];
-                    } else {
-                        gload_words<3>(ovQ + 3u * (m - (uint32_t)SH::CAPQ_REC), q);
-                    }
-                    const uint32_t own = q[0] & 1023u, ord = (q[0] >> 10) & 15u;
-                    const uint32_t f = lng(rec16(q[1] & 0xffffu)) | (lng(rec16(q[1] >> 16)) << 1) | (lng(rec16(q[2] & 0xffffu)) << 2) |
-                                       (lng(rec16(q[2] >> 16)) << 3);
-                    if (f) ex.lds_or(&sh.lq[own][ord >> 3], f << (4u * (ord & 7u)));
+                    for (int i = 0; i < 3; i++) q[i] = sh.pool[SH::QBASE + 3u * m + i];
+                } else {
+                    gload_words<3>(ovQ + 3u * (m - (uint32_t)SH::CAPQ_REC), q);
                 }
-                for (uint32_t k = (uint32_t)tid; k < stI; k += NT) {
-                    uint32_t rec[5];
-                    if (k < (uint32_t)SH::CAPI_REC) {
+                const uint32_t own = q[0] & 1023u, ord = (q[0] >> 10) & 15u;
+                const uint32_t f = lng(rec16(q[1] & 0xffffu)) | (lng(rec16(q[1] >> 16)) << 1) | (lng(rec16(q[2] & 0xffffu)) << 2) |
+                                   (lng(rec16(q[2] >> 16)) << 3);
+                if (f) ex.lds_or(&sh.lq[own][ord >> 3], f << (4u * (ord & 7u)));
+            }
+            for (uint32_t k = first; k < stI; k += step) {
+                uint32_t rec[5];
+                if (k < (uint32_t)SH::CAPI_REC) {
 #pragma unroll
-                        for (int i = 0; i < 5; i++) rec[i] = sh.pool[5u * k + i];
-                    } else {
-                        gload_words<5>(ovI + 5u * (k - (uint32_t)SH::CAPI_REC), rec);
-                    }
-                    const uint32_t own = rec[0] & 1023u, ord2 = (rec[0] >> 10) & 3u, tb1 = (rec[0] >> 16) & 15u;
-                    uint32_t f = 0;
+                    for (int i = 0; i < 5; i++) rec[i] = sh.pool[5u * k + i];
+                } else {
+                    gload_words<5>(ovI + 5u * (k - (uint32_t)SH::CAPI_REC), rec);
+                }
+                const uint32_t own = rec[0] & 1023u, ord2 = (rec[0] >> 10) & 3u, tb1 = (rec[0] >> 16) & 15u;
+                uint32_t f = 0;
 #pragma unroll
-                    for (int qq = 0; qq < 4; qq++) {
-                        f |= lng(rec16(rec[1 + qq] & 0xffffu)) << qq;                                   // Lmax of quad qq
-                        f |= (((tb1 >> (3 - qq)) & 1u) & lng(rec16(rec[1 + qq] >> 16))) << (4 + qq);     // Lmin, internal quads only
+                for (int qq = 0; qq < 4; qq++) {
+                    f |= lng(rec16(rec[1 + qq] & 0xffffu)) << qq;                                   // Lmax of quad qq
+                    f |= (((tb1 >> (3 - qq)) & 1u) & lng(rec16(rec[1 + qq] >> 16))) << (4 + qq);     // Lmin, internal quads only
+                }
+                if (f) ex.lds_or(&sh.li[own], f << (8u * ord2));
+            }
+        };
+        // records that overflowed to global scratch are read by other threads: their stores must have landed
+        if (have_s && rec_ovf) ex.barrier_global();
+#ifdef K2R_TOPWAVE  // (built, bit-exact and 2.3 % SLOWER than the phased form, 11.48 against 11.22 ms on the same box: off)
+        constexpr bool kTopWave = !EX::kSim && NT > 64;
+#else
+        constexpr bool kTopWave = false;
+#endif
+        if (kTopWave && have_s) {
+            // The GPU form for logs (sidelen 128 and 256).  The tree top as five barrier-separated LDS phases kept fifteen waves idle
+            // for most of five phases; the pre-pass is sparse work over a few thousand records; neither needs the other.  So ONE wave
+            // builds the whole top -- lane = height-4 node (Morton order: 64 of them per trip, one trip at sidelen 128, four at 256),
+            // the four children read from LDS, heights 5, 6 and 7 reduced in registers over quads, rows and the wave (DPP, readlane),
+            // the root from the four trips' scalars -- while the other fifteen waves run the pre-pass.
+            if constexpr (kTopWave && H >= 7) ex.par([&](int tid, EncRegs&) {
+                if (tid < 64) {
+                    constexpr int TRIPS = 1 << (2 * (H - 7));  // height-7 nodes
+                    int32_t rmin = 0, rmax = 0, rsmin = 0, rsmax = 0, rdiff = 0;
+                    uint32_t rz = 0;
+#pragma unroll 1
+                    for (int i = 0; i < TRIPS; i++) {
+                        const int j4 = 64 * i + tid;
+                        top_node(4, j4);
+                        const int a4 = C::top_off(4) + j4;
+                        int32_t mn = sh.tmin[a4], mx = sh.tmax[a4], sn = sh.smin[a4], sx = sh.smax[a4], df = sh.diff[a4];
+                        uint32_t z = sh.eq[a4] ^ 1u;  // "not equal" so far
+                        // height 5: quads
+                        mn = EX::quad_min(mn); mx = EX::quad_max(mx); sn = EX::quad_min(sn); sx = EX::quad_max(sx);
+                        int32_t d5 = (int32_t)EX::template quad_bcast<0>((uint32_t)df);
+                        z = EX::quad_or(z | (df != d5 ? 1u : 0u));
+                        if ((tid & 3) == 0) {
+                            const int a = C::top_off(5) + (j4 >> 2);
+                            sh.tmin[a] = mn; sh.tmax[a] = mx; sh.smin[a] = sn; sh.smax[a] = sx; sh.diff[a] = d5; sh.eq[a] = z ^ 1u;
+                        }
+                        // height 6: rows of sixteen lanes
+                        mn = EX::row_min_of_quads(mn); mx = EX::row_max_of_quads(mx); sn = EX::row_min_of_quads(sn); sx = EX::row_max_of_quads(sx);
+                        const int32_t d6 = (int32_t)EX::lane_pull((uint32_t)tid & 48u, (uint32_t)d5);
+                        z = EX::row_or_of_quads(z | (d5 != d6 ? 1u : 0u));
+                        if ((tid & 15) == 0) {
+                            const int a = C::top_off(6) + (j4 >> 4);
+                            sh.tmin[a] = mn; sh.tmax[a] = mx; sh.smin[a] = sn; sh.smax[a] = sx; sh.diff[a] = d6; sh.eq[a] = z ^ 1u;
+                        }
+                        // height 7: the wave (scalars)
+                        const int32_t mn7 = EX::wave_min_of_rows(mn), mx7 = EX::wave_max_of_rows(mx), sn7 = EX::wave_min_of_rows(sn),
+                                      sx7 = EX::wave_max_of_rows(sx), d7 = (int32_t)ex.lane_value((uint32_t)d6, 0);
+                        const uint32_t z7 = EX::wave_or_of_rows(z | (d6 != d7 ? 1u : 0u));
+                        if (tid == 0) {
+                            const int a = C::top_off(7) + i;
+                            sh.tmin[a] = mn7; sh.tmax[a] = mx7; sh.smin[a] = sn7; sh.smax[a] = sx7; sh.diff[a] = d7; sh.eq[a] = z7 ^ 1u;
+                        }
+                        // height 8: the root, from the trips
+                        rmin = i == 0 ? mn7 : (mn7 < rmin ? mn7 : rmin);
+                        rmax = i == 0 ? mx7 : (mx7 > rmax ? mx7 : rmax);
+                        rsmin = i == 0 ? sn7 : (sn7 < rsmin ? sn7 : rsmin);
+                        rsmax = i == 0 ? sx7 : (sx7 > rsmax ? sx7 : rsmax);
+                        if (i == 0) rdiff = d7;
+                        rz |= z7 | (d7 != rdiff ? 1u : 0u);
                     }
-                    if (f) ex.lds_or(&sh.li[own], f << (8u * ord2));
+                    if (H == 8 && tid == 0) {
+                        const int a = C::top_off(H);
+                        sh.tmin[a] = rmin; sh.tmax[a] = rmax; sh.smin[a] = rsmin; sh.smax[a] = rsmax; sh.diff[a] = rdiff; sh.eq[a] = rz ^ 1u;
+                    }
+                } else if (!(K2R_DIAG_SKIP & 64)) {
+                    prepass((uint32_t)tid - 64u, (uint32_t)NT - 64u);
                 }
             });
-            if (H < 4) ex.barrier();  // (phase 3 reads the flags; taller trees have phase 2's barriers in between)
-        }
-
-        // ================= phase 2: heights 4..H in LDS (snapshot.rs:476-497, log.rs:776-806) ==========
-        for (int h = 4; h <= H; h++) {
-            const int n_h = 1 << (2 * (H - h));
-            const int co = C::top_off(h - 1), po = C::top_off(h);
-            ex.par([&](int tid, EncRegs&) {
-                for (int j = tid; j < n_h; j += NT) {
-                    const int c = co + 4 * j;
-                    sh.tmin[po + j] = min4(sh.tmin[c], sh.tmin[c + 1], sh.tmin[c + 2], sh.tmin[c + 3]);
-                    sh.tmax[po + j] = max4(sh.tmax[c], sh.tmax[c + 1], sh.tmax[c + 2], sh.tmax[c + 3]);
-                    if (have_s) {
-                        sh.smin[po + j] = min4(sh.smin[c], sh.smin[c + 1], sh.smin[c + 2], sh.smin[c + 3]);
-                        sh.smax[po + j] = max4(sh.smax[c], sh.smax[c + 1], sh.smax[c + 2], sh.smax[c + 3]);
-                        const int32_t d0 = sh.diff[c];
-                        sh.diff[po + j] = d0;
-                        sh.eq[po + j] = (sh.eq[c] & sh.eq[c + 1] & sh.eq[c + 2] & sh.eq[c + 3]) &&
-                                                d0 == sh.diff[c + 1] && d0 == sh.diff[c + 2] && d0 == sh.diff[c + 3]
-                                            ? 1u
-                                            : 0u;
-                    }
-                }
-            });
+        } else {
+            if (have_s) {
+                if (!(K2R_DIAG_SKIP & 64)) ex.par_nosync([&](int tid, EncRegs&) { prepass((uint32_t)tid, (uint32_t)NT); });
+                if (H < 4) ex.barrier();  // (phase 3 reads the flags; taller trees have phase 2's barriers in between)
+            }
+            // ================= phase 2: heights 4..H in LDS ==========
+            for (int h = 4; h <= H; h++) {
+                const int n_h = 1 << (2 * (H - h));
+                ex.par([&](int tid, EncRegs&) {
+                    for (int j = tid; j < n_h; j += NT) top_node(h, j);
+                });
+            }
         }
 
         ex.stamp(1);  // phase 2: top of the tree

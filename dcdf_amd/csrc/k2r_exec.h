@@ -60,6 +60,10 @@ struct GpuExec {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         pw_after();
     }
+    // Orders this wave's LDS stores before its later LDS loads ACROSS lanes (the LDS executes a wave's operations in order; the
+    // compiler and the wait counter just have to keep them in program order): what one wave needs between two levels of a tree it
+    // builds alone.
+    __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     __device__ __forceinline__ void barrier_global() {
         pw_before();
         __syncthreads();
@@ -277,6 +281,45 @@ struct GpuExec {
         x |= quad_perm<0xB1>(x);
         return x | quad_perm<0x4E>(x);
     }
+    // rows of 16 lanes: row_ror<N> rotates a row by N lanes (DPP); the reductions leave the result in all sixteen lanes and expect
+    // the value to be uniform over each quad already
+    template <int N>
+    __device__ __forceinline__ static uint32_t row_ror(uint32_t v) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, true);
+    }
+    __device__ __forceinline__ static int32_t row_min_of_quads(int32_t x) {
+        int32_t y = (int32_t)row_ror<4>((uint32_t)x);
+        x = x < y ? x : y;
+        y = (int32_t)row_ror<8>((uint32_t)x);
+        return x < y ? x : y;
+    }
+    __device__ __forceinline__ static int32_t row_max_of_quads(int32_t x) {
+        int32_t y = (int32_t)row_ror<4>((uint32_t)x);
+        x = x > y ? x : y;
+        y = (int32_t)row_ror<8>((uint32_t)x);
+        return x > y ? x : y;
+    }
+    __device__ __forceinline__ static uint32_t row_or_of_quads(uint32_t x) {
+        x |= row_ror<4>(x);
+        return x | row_ror<8>(x);
+    }
+    // ... and the four rows of a wave, for values uniform over each row: scalar results
+    __device__ __forceinline__ static int32_t wave_min_of_rows(int32_t x) {
+        const int32_t a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32),
+                      d = __builtin_amdgcn_readlane(x, 48);
+        const int32_t p = a < b ? a : b, q = c < d ? c : d;
+        return p < q ? p : q;
+    }
+    __device__ __forceinline__ static int32_t wave_max_of_rows(int32_t x) {
+        const int32_t a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32),
+                      d = __builtin_amdgcn_readlane(x, 48);
+        const int32_t p = a > b ? a : b, q = c > d ? c : d;
+        return p > q ? p : q;
+    }
+    __device__ __forceinline__ static uint32_t wave_or_of_rows(uint32_t x) {
+        return (uint32_t)(__builtin_amdgcn_readlane((int)x, 0) | __builtin_amdgcn_readlane((int)x, 16) | __builtin_amdgcn_readlane((int)x, 32) |
+                          __builtin_amdgcn_readlane((int)x, 48));
+    }
     // the value v of lane `src` (0..63) of this wave (ds_bpermute: the LDS crossbar, no LDS memory)
     __device__ __forceinline__ static uint32_t lane_pull(uint32_t src, uint32_t v) {
         return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
@@ -369,6 +412,7 @@ struct SimExec {
         for (int t = 0; t < NT; t++) f(t, regs[t]);
     }
     void barrier() {}
+    void wave_lds_fence() {}
     void barrier_global() {}
     void publish(uint32_t* flag, uint32_t value, uint32_t payload) {
         flag[1] = payload;

@@ -2,7 +2,7 @@
 # round 4, experiment I: what does a Snapshot instant cost next to a Log instant?  (config1 chunks of 1, 2, 3, 5 instants)
 O=gpurun_out/r04i; mkdir -p $O
 for t in 1 2 3 5 9; do
-python bench.py --no-gather --cpu-sample 0 --host-sample 0 --verify 0 --steps 5 --warmup 2 --workload config1 --chunks 4096 --instants $t > $O/t$t.json 2> $O/t$t.err || { tail -5 $O/t$t.err; exit 1; }
+python bench.py --no-gather --cpu-sample 0 --host-sample 0 --verify 0 --steps 5 --warmup 2 --workload config1 --chunks 4096 --instants $t ${EXTRA_ARGS:-} > $O/t$t.json 2> $O/t$t.err || { tail -5 $O/t$t.err; exit 1; }
 done
 python - <<'PY'
 import json,glob
