@@ -7,7 +7,7 @@ TAG=${1:-rXX}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/sq $OUT/sq2
-B="python3 bench.py --cpu-sample 0 --host-sample 0 --verify 1 --no-gather ${BENCH_ARGS:-}"
+B="python3 bench.py --cpu-sample 0 --host-sample 0 --verify 1 --no-gather --decode-queries 0 --also= ${BENCH_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B > $OUT/write.log 2>&1 || exit 1
