@@ -61,10 +61,12 @@ def parse_args(argv=None):
     ap.add_argument("--verify", type=int, default=4, help="chunks compared byte-for-byte with the oracle (untimed)")
     ap.add_argument("--no-gather", action="store_true", help="skip the host-side gather + SHA-256 (profiling runs)")
     ap.add_argument("--pad-elems", type=int, default=0, help="config1: extra elements between consecutive chunks in HBM")
-    ap.add_argument("--dataset", choices=["model", "noise"], default="model",
+    ap.add_argument("--dataset", choices=["model", "noise", "wide"], default="model",
                     help="model: the SURVEY 8(d) value model (default, the headline workload).  noise: iid U[0, 2^30) cells -- the "
                          "adversarial set of SURVEY 8(d): every instant's Snapshot wins chunk.rs:62, i.e. the general (re-reading) "
-                         "emission path and one-instant blocks; a throughput figure for that path, never the headline")
+                         "emission path and one-instant blocks; a throughput figure for that path, never the headline.  wide: the "
+                         "model raster times 300 -- log differences need three bytes and the snapshots' ranges exceed 16 bits (no compact "
+                         "copy), logs still win chunk.rs:62: the general path's LOG side")
     ap.add_argument("--host-sample", type=int, default=1024, help="chunks pushed through the host-buffer entry point for the "
                     "PCIe-inclusive end-to-end figure (0 = skip); 1024 chunks = 8.6 GB of int32 input: long enough for the pinned "
                     "double buffers of the upload and of the download to reach their steady state")
@@ -221,6 +223,9 @@ def main():
         g.manual_seed(0xDCDF0006 + rank)
         flat.copy_(torch.randint(0, 1 << 30, (flat.numel(),), generator=g, device="cuda", dtype=torch.int64).to(tdt))
         workload += "; cells replaced by iid U[0, 2^30) noise (--dataset noise)"
+    if args.dataset == "wide":
+        flat.mul_(300)
+        workload += "; cells multiplied by 300 (--dataset wide: three-byte log values, no compact snapshot copy)"
     torch.cuda.synchronize()
     if args.dtype in ("f32", "f64"):  # the same integers as exact multiples of 2^-fbits in floating point (|v| < 2^24)
         fb = args.fbits

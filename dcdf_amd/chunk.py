@@ -122,12 +122,14 @@ class Chunk:
         hs = (C.c_void_p * n)()
         st = (C.c_int32 * n)()
         L.check(L.lib().dcdf_chunk_open_batch(ptrs, lens, C.c_size_t(n), L.MEM_DEVICE, hs, st), "chunk_open_batch")
+        bad = next((j for j in range(n) if st[j] != 0), None)
+        if bad is not None:  # every handle the call did hand out goes back (the chunks behind `bad` too: they share the slab)
+            for j in range(n):
+                if hs[j]:
+                    L.lib().dcdf_chunk_close(C.c_void_p(hs[j]))
+            raise L.DcdfError(st[bad], "chunk_open_batch: chunk %d" % bad)
         out = []
         for j in range(n):
-            if st[j] != 0:
-                for o in out:
-                    o.close()
-                raise L.DcdfError(st[j], "chunk_open_batch: chunk %d" % j)
             c = cls.__new__(cls)
             c._bytes = None
             c._fetch = (lambda j=j: fetch(j)) if fetch else None

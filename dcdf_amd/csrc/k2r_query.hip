@@ -407,6 +407,236 @@ k_window_wave(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ i
 }
 
 
+// ---- pruned search, any arity with k * k <= 64 -------------------------------------------------------------------------
+// The reference's search is a pruned descent (snapshot.rs:347-421, log.rs:553-702): a subtree whose [min, max] misses [lower, upper]
+// is skipped, one that lies inside is reported whole.  The same walk as k_window_wave -- lane = (frontier node, child), level by
+// level, frontier in LDS -- carrying the node's exact extremes: max_t = Lmax_t + max_s as the window walk has it, and
+// min_t = Lmin_t[rank(T_t, i)] + min_s for a node that is internal in the log (log.rs:148), min_s + (max_t - max_s) where the log
+// is "equal" or has ended (t = s + constant there), with min_s carried down the snapshot (Lmin_s[rank(T_s, i)] = child_min -
+// parent_min for internal nodes, snapshot.rs:140; min = max for its leaves).  Matches are bits of the search item's flat window
+// bitmap.  The result set is the reference's wherever its bounds are true bounds; the one shape where they are not (SearchExtra:
+// single-node uniform log over a multi-node snapshot) is evaluated as the data it is, on the snapshot with the root's difference.
+struct SearchExtra {
+    int64_t lower, upper;
+    // The reference's Log::search_window has no case for a single-node UNIFORM log over a multi-node snapshot (log.rs:527-548):
+    // it never reads eqB[0], seeds min_t with an empty Dac's 0 and descends the snapshot as if the log were "equal" with the
+    // root's difference.  Read as data, its result for such an instant is: every cell when min_s(root) >= lower and c <= upper
+    // (c = the instant's one value), no cell when min_s(root) > upper or c < lower, and otherwise the cells with
+    // lower <= s(cell) + (c - max_s(root)) <= upper.  quirk != 0 makes the walk do exactly that instead of the decode of the
+    // instant's true values.
+    uint32_t quirk, _pad;
+};
+struct SearchSt {
+    uint32_t bt, bs;
+    int64_t mt, ms, mns;  // max_t - max_s so far / max_s / min_s of the node
+};
+struct WaveQS {
+    uint32_t it[WQ_CAP], is[WQ_CAP], org[WQ_CAP];
+    int64_t mt[WQ_CAP], ms[WQ_CAP], mns[WQ_CAP];
+};
+// child c of node p: true = the child's square holds ONE value (*mx); else its state in *o and its extremes in *mn / *mx
+__device__ __forceinline__ bool search_child(const uint8_t* b, const InstDesc& S, const InstDesc* L, const SearchSt& p, uint32_t c, uint32_t k2,
+                                             SearchSt* o, int64_t* mn, int64_t* mx) {
+    const bool has_t = p.bt != WQ_NONE, has_s = p.bs != WQ_NONE;
+    const uint32_t it_ = has_t ? p.bt + c : 0u, is_ = has_s ? p.bs + c : 0u;
+    const int64_t mt_ = has_t ? dacd_get(b, L->mx, it_) : p.mt;
+    const int64_t ms_ = has_s ? p.ms - dacd_get(b, S.mx, is_) : p.ms;
+    const bool leaf_t = has_t ? (it_ >= L->T.len || !bmd_get(b, L->T, it_)) : true;
+    const bool leaf_s = has_s ? (is_ >= S.T.len || !bmd_get(b, S.T, is_)) : true;
+    const uint32_t rt = has_t ? bmd_rank(b, L->T, it_) : 0u, rs = has_s ? bmd_rank(b, S.T, is_) : 0u;
+    const int64_t mns_ = has_s ? (leaf_s ? ms_ : p.mns + dacd_get(b, S.mn, rs)) : p.mns;
+    *mx = mt_ + ms_;
+    *mn = (has_t && !leaf_t) ? dacd_get(b, L->mn, rt) + mns_ : mt_ + mns_;
+    if (leaf_t && leaf_s) return true;
+    o->mt = mt_;
+    o->ms = ms_;
+    o->mns = mns_;
+    if (leaf_s) {
+        o->bt = 1 + rt * k2;
+        o->bs = WQ_NONE;
+        return false;
+    }
+    if (leaf_t) {
+        if (has_t && !bmd_get(b, L->E, it_ - rt)) return true;  // uniform, not "equal" (log.rs:452-467)
+        o->bt = WQ_NONE;
+        o->bs = 1 + rs * k2;
+        return false;
+    }
+    o->bt = 1 + rt * k2;
+    o->bs = 1 + rs * k2;
+    return false;
+}
+__global__ void __launch_bounds__(256)
+k_search_wave(const ChunkRef* __restrict__ chunks, const WinItem* __restrict__ items, uint32_t n_items, const SearchExtra* __restrict__ sx,
+              uint32_t* __restrict__ bits, uint32_t* __restrict__ counts) {
+    __shared__ WaveQS wq[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveQS& q = wq[wave];
+    for (uint32_t item = blockIdx.x * 4u + (uint32_t)wave; item < n_items; item += gridDim.x * 4u) {
+        const WinItem I = items[item];
+        const SearchExtra X = sx[item];
+        const ChunkRef C = chunks[I.chunk];
+        const uint8_t* const b = C.bytes;
+        const InstDesc& D = C.descs[I.inst];
+        const bool quirk = X.quirk != 0;
+        const bool has_log = D.is_log != 0 && !quirk;
+        const InstDesc& S = D.is_log != 0 ? C.descs[D.snap] : D;
+        const InstDesc* const L = has_log ? &D : nullptr;
+        const uint32_t k = D.k, k2 = k * k;
+        const uint32_t wtop = I.top, wbot = I.bottom, wleft = I.left, wright = I.right;
+        const int64_t lower = X.lower, upper = X.upper;
+        uint32_t cnt = 0;
+        // I.out_off = bit index of cell (top, left) in the item's flat window bitmap, I.out_sr = the window's width
+        auto mark = [&](uint32_t r, uint32_t c) {
+            const uint64_t e = I.out_off + (uint64_t)(r - wtop) * I.out_sr + (c - wleft);
+            atomicOr(&bits[e >> 5], 1u << (e & 31u));
+            cnt++;
+        };
+        auto mark_wave = [&](uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1) {
+            const uint32_t w = c1 - c0, area = (r1 - r0) * w;
+            for (uint32_t i = (uint32_t)lane; i < area; i += 64) mark(r0 + i / w, c0 + i % w);
+        };
+        // ---- roots ----
+        const bool single_s = !bmd_get(b, S.T, 0);
+        const bool single_t = has_log ? !bmd_get(b, L->T, 0) : true;
+        const int64_t max_s0 = dacd_get(b, S.mx, 0), min_s0 = single_s ? max_s0 : dacd_get(b, S.mn, 0);  // (a leaf root has no Lmin entry)
+        int64_t max_t0 = has_log ? dacd_get(b, L->mx, 0) : 0;
+        bool done = false;
+        if (quirk) {  // (log.rs:527-586 on this shape: SearchExtra)
+            const int64_t c1 = dacd_get(b, D.mx, 0) + max_s0;
+            if (min_s0 >= lower && c1 <= upper) {
+                mark_wave(wtop, wbot, wleft, wright);
+                done = true;
+            } else if (min_s0 > upper || c1 < lower) {
+                done = true;
+            }
+            max_t0 = c1 - max_s0;  // the walk below: s(cell) + (c - max_s(root))
+        } else {
+            const bool all_one = has_log ? (single_t && (single_s || !bmd_get(b, L->E, 0))) : single_s;
+            if (all_one) {
+                const int64_t v = max_t0 + max_s0;
+                if (lower <= v && v <= upper) mark_wave(wtop, wbot, wleft, wright);
+                done = true;
+            }
+        }
+        if (!done) {
+            if (lane == 0) {
+                q.it[0] = (has_log && !single_t) ? 1u : WQ_NONE;
+                q.is[0] = single_s ? WQ_NONE : 1u;
+                q.org[0] = 0;
+                q.mt[0] = max_t0;
+                q.ms[0] = max_s0;
+                q.mns[0] = min_s0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t lo = 0, hi = 1, side = D.sidelen;
+            const uint32_t per = 64u / k2;
+            const uint32_t myn = (uint32_t)lane / k2, myc = (uint32_t)lane % k2;
+            while (side > k2) {
+                const uint32_t cs = side / k;
+                uint32_t next = hi;
+                for (uint32_t base = lo; base < hi; base += per) {
+                    const uint32_t n = base + myn;
+                    const bool live = myn < per && n < hi;
+                    bool push = false, fill = false;
+                    SearchSt o{};
+                    uint32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, org = 0;
+                    if (live) {
+                        const SearchSt p{q.it[n], q.is[n], q.mt[n], q.ms[n], q.mns[n]};
+                        const uint32_t po = q.org[n];
+                        const uint32_t cr = (po >> 16) + (myc / k) * cs, cc = (po & 0xffffu) + (myc % k) * cs;
+                        r0 = cr > wtop ? cr : wtop; r1 = cr + cs < wbot ? cr + cs : wbot;
+                        c0 = cc > wleft ? cc : wleft; c1 = cc + cs < wright ? cc + cs : wright;
+                        if (r0 < r1 && c0 < c1) {
+                            int64_t mn = 0, mx = 0;
+                            const bool one = search_child(b, S, L, p, myc, k2, &o, &mn, &mx);
+                            if (one) fill = lower <= mx && mx <= upper;
+                            else if (mx < lower || mn > upper) fill = false;      // nothing of this subtree is in range
+                            else if (mn >= lower && mx <= upper) fill = true;     // all of it is
+                            else push = true;
+                            org = (cr << 16) | cc;
+                        }
+                    }
+                    const unsigned long long bp = __builtin_amdgcn_ballot_w64(push);
+                    if (push) {
+                        const uint32_t pos = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bp, 0u));
+                        if (pos < (uint32_t)WQ_CAP) {
+                            q.it[pos] = o.bt; q.is[pos] = o.bs; q.org[pos] = org; q.mt[pos] = o.mt; q.ms[pos] = o.ms; q.mns[pos] = o.mns;
+                        }
+                    }
+                    next += (uint32_t)__builtin_popcountll(bp);
+                    const bool small = (r1 - r0) * (c1 - c0) <= 4;
+                    if (fill && small)
+                        for (uint32_t r = r0; r < r1; r++)
+                            for (uint32_t c = c0; c < c1; c++) mark(r, c);
+                    unsigned long long bf = __builtin_amdgcn_ballot_w64(fill && !small);
+                    while (bf) {
+                        const int l = __builtin_ctzll(bf);
+                        bf &= bf - 1;
+                        const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)((r0 << 16) | r1), l);
+                        const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)((c0 << 16) | c1), l);
+                        mark_wave(rr >> 16, rr & 0xffffu, cc >> 16, cc & 0xffffu);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                lo = hi;
+                hi = next < (uint32_t)WQ_CAP ? next : (uint32_t)WQ_CAP;
+                side = cs;
+            }
+            // ---- the last two levels ----
+            {
+                const uint32_t cs = side / k;
+                for (uint32_t base = lo; base < hi; base += per) {
+                    const uint32_t n = base + myn;
+                    if (!(myn < per && n < hi)) continue;
+                    const SearchSt p{q.it[n], q.is[n], q.mt[n], q.ms[n], q.mns[n]};
+                    const uint32_t po = q.org[n];
+                    const uint32_t cr = (po >> 16) + (myc / k) * cs, cc = (po & 0xffffu) + (myc % k) * cs;
+                    const uint32_t r0 = cr > wtop ? cr : wtop, r1 = cr + cs < wbot ? cr + cs : wbot;
+                    const uint32_t c0 = cc > wleft ? cc : wleft, c1 = cc + cs < wright ? cc + cs : wright;
+                    if (!(r0 < r1 && c0 < c1)) continue;
+                    SearchSt o{};
+                    int64_t mn = 0, mx = 0;
+                    const bool one = search_child(b, S, L, p, myc, k2, &o, &mn, &mx);
+                    if (one || cs == 1) {  // (a cell is always a leaf of both trees)
+                        if (lower <= mx && mx <= upper)
+                            for (uint32_t r = r0; r < r1; r++)
+                                for (uint32_t c = c0; c < c1; c++) mark(r, c);
+                        continue;
+                    }
+                    if (mx < lower || mn > upper) continue;
+                    if (mn >= lower && mx <= upper) {
+                        for (uint32_t r = r0; r < r1; r++)
+                            for (uint32_t c = c0; c < c1; c++) mark(r, c);
+                        continue;
+                    }
+                    const int64_t shift = quirk ? max_t0 : 0;  // (per-cell descents below decode the true instant; the quirk walks the snapshot)
+                    if (cs != k) {  // sidelen not a power of k (malformed input): plain per-cell descents
+                        for (uint32_t r = r0; r < r1; r++)
+                            for (uint32_t c = c0; c < c1; c++) {
+                                const int64_t v = inst_get(b, C.descs, quirk ? D.snap : I.inst, r, c) + shift;
+                                if (lower <= v && v <= upper) mark(r, c);
+                            }
+                        continue;
+                    }
+                    for (uint32_t r = r0; r < r1; r++)
+                        for (uint32_t c = c0; c < c1; c++) {
+                            SearchSt oo{};
+                            int64_t vn = 0, v = 0;
+                            (void)search_child(b, S, L, o, (r - cr) * k + (c - cc), k2, &oo, &vn, &v);
+                            if (lower <= v && v <= upper) mark(r, c);
+                        }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the item's count: this wave's matches, summed over its lanes
+        for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_down(cnt, o2, 64);
+        if (lane == 0 && cnt) atomicAdd(&counts[X._pad], cnt);
+    }
+}
+
 // ---- k = 2, node-wise: one lane per frontier NODE, its four children share their loads ---------------------------------
 // Siblings are adjacent in every stream (children of a node sit at base .. base + 3): their four T bits and ranks come from
 // ONE 16-byte load of the rank block (+ its index word), their four Lmax bytes from ONE 4-byte load, their continuation bits
@@ -584,16 +814,6 @@ typedef WaveQ2T<int64_t> WaveQ2;
 // What a search item adds to its WinItem (search = the same walk; instead of storing a cell it tests lower <= v <= upper and
 // sets the cell's bit in the item's own bitmap -- 64 rows x 2 words: word = 2 * (row - top) + (column - left) / 32 -- at out[item * 128];
 // no two waves share a word, so there is nothing atomic about it and nothing to clear beforehand).
-struct SearchExtra {
-    int64_t lower, upper;
-    // The reference's Log::search_window has no case for a single-node UNIFORM log over a multi-node snapshot (log.rs:527-548):
-    // it never reads eqB[0], seeds min_t with an empty Dac's 0 and descends the snapshot as if the log were "equal" with the
-    // root's difference.  Read as data, its result for such an instant is: every cell when min_s(root) >= lower and c <= upper
-    // (c = the instant's one value), no cell when min_s(root) > upper or c < lower, and otherwise the cells with
-    // lower <= s(cell) + (c - max_s(root)) <= upper.  quirk != 0 makes the walk do exactly that instead of the decode of the
-    // instant's true values.
-    uint32_t quirk, _pad;
-};
 // MW = waves per SIMD the register allocator must leave room for (4 for the 32-bit walk; the 64-bit one's frontier leaves LDS
 // for 3 workgroups per CU, so it is built for 3); DENSE64: the batched form's output (int64, unit column stride);
 // SEARCH: mark matches (out = the bitmaps, sx = one SearchExtra per item) instead of storing values
@@ -1865,6 +2085,7 @@ struct SearchCtx {  // a raster's view of its chunks (dcdf_raster_search_batch):
     const uint32_t* chunk_of;  // per query: index into it
     const uint32_t* origin;    // per query: (instant, row, col) of the chunk inside the raster, added to every triple
     bool node_wise, all_narrow;
+    bool wave_ok;              // every chunk has k * k <= 64 (k_search_wave for the arities the node walk does not take)
 };
 
 static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const int64_t* lower, const int64_t* upper,
@@ -1881,6 +2102,11 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
     bool node_wise = std::getenv("K2R_SEARCH_DFS") == nullptr;  // (diagnostics: A/B against the cell-by-cell kernel)
     for (const dcdf_chunk* u : uniq) node_wise = node_wise && node_kernel_ok(u);
     if (ctx) node_wise = node_wise && ctx->node_wise;
+    // other arities with k * k <= 64: the pruned wave walk k_search_wave, one wave per (item, sub-window of <= 32 x 32 cells), into the
+    // item's flat window bitmap; what is left (k > 8) is decoded and tested cell by cell
+    bool wave_search = !node_wise && std::getenv("K2R_SEARCH_CELLS") == nullptr;
+    for (const dcdf_chunk* u : uniq) wave_search = wave_search && wave_kernel_ok(u);
+    if (ctx) wave_search = wave_search && ctx->wave_ok;
     std::vector<WinItem> witems;
     std::vector<SearchExtra> sx;
     std::vector<uint8_t> item_quirk;  // per item of the decode-and-test kernel
@@ -1923,6 +2149,24 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
                 items.push_back(SearchItem{(uint32_t)q, i, bits_words, SI_FLAT, 0});
                 item_quirk.resize(items.size(), 0);
                 item_quirk.back() = chunks[q]->search_quirk[i];
+                if (wave_search) {
+                    if (witems.size() + 4096 > 0xffffff00u) return DCDF_ERR_CAPACITY;
+                    const uint32_t wc = c.right - c.left;
+                    for (uint32_t r = c.top & ~31u; r < c.bottom; r += 32)
+                        for (uint32_t cc = c.left & ~31u; cc < c.right; cc += 32) {
+                            WinItem it{};
+                            it.chunk = Q.chunk;
+                            it.inst = i;
+                            it.top = (uint16_t)std::max(r, c.top);
+                            it.bottom = (uint16_t)std::min(r + 32, c.bottom);
+                            it.left = (uint16_t)std::max(cc, c.left);
+                            it.right = (uint16_t)std::min(cc + 32, c.right);
+                            it.out_sr = wc;  // bit (r, c) of the item's bitmap = out_off + (r - top) * out_sr + (c - left)
+                            it.out_off = bits_words * 32ull + (uint64_t)(it.top - c.top) * wc + (it.left - c.left);
+                            witems.push_back(it);
+                            sx.push_back(SearchExtra{Q.lower, Q.upper, chunks[q]->search_quirk[i] ? 1u : 0u, (uint32_t)(items.size() - 1)});
+                        }
+                }
                 bits_words += (cells + 31) / 32;
                 n_dfs++;
             }
@@ -1952,15 +2196,19 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
             K2R_HIP(hipMemcpy(d_witems.p, witems.data(), witems.size() * sizeof(WinItem), hipMemcpyHostToDevice));
             K2R_HIP(d_sx.alloc(sx.size() * sizeof(SearchExtra)));
             K2R_HIP(hipMemcpy(d_sx.p, sx.data(), sx.size() * sizeof(SearchExtra), hipMemcpyHostToDevice));
-            K2R_HIP(d_wbits.alloc((size_t)nw * 512));  // (every word is written by the walk: nothing to clear)
+            if (node_wise) K2R_HIP(d_wbits.alloc((size_t)nw * 512));  // (every word is written by the walk: nothing to clear)
         }
         K2R_HIP(d_counts.alloc(items.size() * 4));
+        if (wave_search) K2R_HIP(hipMemset(d_counts.p, 0, items.size() * 4));  // (several waves add to an item's count)
         EventPair ev;
         K2R_HIP(ev.create());
         const hipEvent_t e0 = ev.e0, e1 = ev.e1;
         const uint32_t ni = (uint32_t)items.size();
         K2R_HIP(hipEventRecord(e0, 0));
-        if (nw) {
+        if (nw && wave_search) {
+            hipLaunchKernelGGL(k_search_wave, dim3(std::min<uint32_t>((nw + 3) / 4, 256u * 16u)), dim3(256), 0, 0, d_refs.as<ChunkRef>(),
+                               d_witems.as<WinItem>(), nw, d_sx.as<SearchExtra>(), d_bits.as<uint32_t>(), d_counts.as<uint32_t>());
+        } else if (nw) {
             bool all_narrow = true;
             for (const dcdf_chunk* u : uniq) all_narrow = all_narrow && u->narrow32;
             if (ctx) all_narrow = ctx->all_narrow;
@@ -1973,7 +2221,7 @@ static int search_impl(dcdf_chunk* const* chunks, const dcdf_cube* cubes, const 
             hipLaunchKernelGGL(k_search_count, dim3((ni + 63) / 64), dim3(64), 0, 0, d_wbits.as<uint32_t>(), d_items.as<SearchItem>(),
                                d_qs.as<WinQuery>(), ni, d_counts.as<uint32_t>());
         }
-        if (n_dfs) {
+        if (n_dfs && !wave_search) {
             item_quirk.resize(items.size(), 0);
             K2R_HIP(d_quirk.alloc(items.size()));
             K2R_HIP(hipMemcpy(d_quirk.p, item_quirk.data(), items.size(), hipMemcpyHostToDevice));
@@ -2156,6 +2404,10 @@ extern "C" int dcdf_query_fill_window_batch_typed(dcdf_chunk* const* chunks, con
 // caller's window (the pieces carry the parent window's strides): no per-piece copies, no reassembly, the chunk table uploaded once.
 struct dcdf_raster {
     std::vector<dcdf_chunk*> chunks;  // [(segment * nti + ti) * ntj + tj]
+    // d_refs holds device pointers into the chunks' streams and tables: the raster shares the ownership of every slab a batch-opened
+    // chunk lives in (dcdf_chunk::store), so closing such a chunk first leaves the raster usable; chunks opened one by one own their
+    // buffers themselves and must outlive the raster (dcdf_k2r.h)
+    std::vector<std::shared_ptr<void>> keep;
     uint32_t T = 0, R = 0, C = 0, tile = 0, cs = 0, nseg = 0, nti = 0, ntj = 0;
     DevBuf d_refs;
     DevBuf d_quirk;  // [chunk][chunk_size]: dcdf_chunk::search_quirk of every instant (k_raster_search_expand)
@@ -2173,6 +2425,8 @@ extern "C" int dcdf_raster_create(dcdf_chunk* const* chunks, size_t n_chunks, co
     r->ntj = (r->C + tile - 1) / tile;
     if ((uint64_t)r->nseg * r->nti * r->ntj != n_chunks) return DCDF_ERR_BAD_ARG;
     r->chunks.assign(chunks, chunks + n_chunks);
+    for (size_t i = 0; i < n_chunks; i++)
+        if (chunks[i] && chunks[i]->store && (r->keep.empty() || r->keep.back() != chunks[i]->store)) r->keep.push_back(chunks[i]->store);
     std::vector<ChunkRef> refs(n_chunks);
     for (size_t i = 0; i < n_chunks; i++) {
         const dcdf_chunk* h = chunks[i];
@@ -2588,7 +2842,7 @@ extern "C" int dcdf_raster_search_batch(const dcdf_raster* r, const dcdf_cube* c
     size_t total = 0;
     // the pieces of one query follow each other (segments, then tile rows, then tile columns) and search_impl emits in
     // query order, so a query's triples are contiguous; each is moved to raster coordinates as it is written
-    const SearchCtx ctx{&r->d_refs, scid.data(), sorg.data(), r->all_node, r->all_narrow};
+    const SearchCtx ctx{&r->d_refs, scid.data(), sorg.data(), r->all_node, r->all_narrow, r->all_wave};
     const int rc = search_impl(sch.data(), scube.data(), slo.data(), shi.data(), sch.size(), out, cap, scnt.data(), soff.data(), &total, kernel_ms,
                                out_mem, &ctx);
     if (rc != DCDF_OK) return rc;

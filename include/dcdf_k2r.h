@@ -223,7 +223,9 @@ int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t* lens, siz
 /* ---- a whole raster of chunks: the routing of the layers above ------------------------------------------------------- */
 /* A variable as dcdf lays it out: time segments of chunk_size instants (Variable::append, dataset.rs:838), each cut into
  * tile x tile sub-arrays (Superchunk::build, superchunk.rs:127-181); chunks[(segment * ntiles_r + ti) * ntiles_c + tj], every chunk
- * with the shape its place gives it.  The handle keeps the chunk table on the device. */
+ * with the shape its place gives it.  The handle keeps the chunk table on the device.  Lifetime: the raster refers to the chunks'
+ * device buffers; it shares the ownership of the slab of chunks opened by dcdf_chunk_open_batch (closing such a chunk first is
+ * fine), chunks opened one by one (dcdf_chunk_open) must stay open until dcdf_raster_destroy. */
 typedef struct dcdf_raster dcdf_raster;
 int dcdf_raster_create(dcdf_chunk* const* chunks, size_t n_chunks, const uint32_t shape[3], uint32_t tile, uint32_t chunk_size,
                        dcdf_raster** out);

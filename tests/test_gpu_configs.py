@@ -380,11 +380,13 @@ def test_raster_entry_points_reject_bad_input(dc):
         c.close()
 
 
-@pytest.mark.parametrize("k,tile", [(3, 81), (4, 64), (2, 300)])
-def test_raster_entry_points_other_arities_and_tiles(dc, k, tile):
+@pytest.mark.parametrize("k,tile,cells", [(3, 81, False), (3, 81, True), (4, 64, False), (2, 300, False)])
+def test_raster_entry_points_other_arities_and_tiles(dc, k, tile, cells, monkeypatch):
     """dcdf_raster_* over chunks that do not take the k = 2 node walk (k = 3, 4: the wave kernel on the chunk's 32-grid, search
-    by decode-and-test with host-built items) and over padded k = 2 tiles wider than one 64-piece: windows and matches against
-    the raw raster."""
+    by the pruned wave walk `k_search_wave`, or -- `cells`: K2R_SEARCH_CELLS=1 -- by the decode-and-test kernel kept for
+    k > 8) and over padded k = 2 tiles wider than one 64-piece: windows and matches against the raw raster."""
+    if cells:
+        monkeypatch.setenv("K2R_SEARCH_CELLS", "1")
     from dcdf_amd import build_batch
     from dcdf_amd.raster import EncodedRaster
     rng = np.random.default_rng(100 + k)

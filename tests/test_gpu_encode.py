@@ -188,6 +188,17 @@ def test_float32_full_size_chunks(dc):
     assert_same(dc, [g], fractional_bits=3, round=True)
 
 
+def test_wide_model_logs(dc):
+    """bench.py --dataset wide in small: the model raster times 300.  Log differences need three bytes (the stash does not take
+    them), the snapshot's range exceeds 16 bits (no compact copy), and logs still win chunk.rs:62: the LOG side of the general path."""
+    from dcdf_amd import synth
+    a = (synth.cells(0xDCDF0003, 0, 8, 256, 512, 512, 768, np.int32).astype(np.int64) * 300).astype(np.int32)
+    res = dc.build_batch([a])
+    assert res[0].snapshots == 1 and res[0].logs == 7
+    assert_same(dc, [a])
+    assert_same(dc, [a.astype(np.int64)])
+
+
 def test_int32_rows_value_range_contract(dc):
     a = np.zeros((2, 16, 16), dtype=np.int32)
     a[1, 9, 9] = 2 ** 30  # outside the fused kernel's contract: re-routed, same bytes as the oracle
