@@ -4,14 +4,18 @@
 // per-class work queues.  dcdf_chunk_build_batch = upload + session + fetch.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include <cstring>
 #include <queue>
@@ -199,7 +203,7 @@ struct dcdf_encoder {
     ~dcdf_encoder() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) StreamPool::get().give(false, stream);
     }
 };
 
@@ -289,7 +293,7 @@ extern "C" int dcdf_encoder_create(const dcdf_tile_desc* tiles, size_t n, int k,
         mm_total += 2ull * t.instants;
     }
     e->minmax_total = mm_total;
-    K2R_HIP(hipStreamCreate(&e->stream));
+    K2R_HIP(StreamPool::get().take(false, &e->stream));
     K2R_HIP(hipEventCreate(&e->ev0));
     K2R_HIP(hipEventCreate(&e->ev1));
     K2R_HIP(e->d_out.alloc_pooled(out_total));
@@ -818,11 +822,15 @@ extern "C" int dcdf_encoder_gather(dcdf_encoder* e, uint8_t* dst, size_t cap, ui
         struct OwnStream {
             hipStream_t s = nullptr;
             ~OwnStream() {
-                if (s) (void)hipStreamDestroy(s);
+                if (s) StreamPool::get().give(true, s);
             }
         } own;
-        K2R_HIP(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
+        K2R_HIP(StreamPool::get().take(true, &own.s));
         DevBuf d_items, d_packed;
+        struct Settle {  // (declared behind the buffers: the stream is idle before an early return hands them back to the pool)
+            hipStream_t s;
+            ~Settle() { (void)hipStreamSynchronize(s); }
+        } settle{own.s};
         K2R_HIP(d_items.alloc(items.size() * sizeof(PackItem)));
         K2R_HIP(d_packed.alloc_pooled(tot));
         K2R_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice, own.s));
@@ -862,11 +870,37 @@ extern "C" void dcdf_free_encoded(dcdf_encoded* out, size_t n) {
 namespace {
 
 constexpr size_t kPinBytes = 64u << 20;
-constexpr int kPackThreads = 8;
+constexpr int kDownSlots = 4;                            // downloads see the two buffers as four slots ...
+constexpr size_t kSlotBytes = 2 * kPinBytes / kDownSlots;  // ... of 32 MB, each with its own event
+
+// Host threads for packing, unpacking and hashing: one and a half per CPU this process may use (they wait on page faults and on
+// the copy engine as much as they compute) -- the cgroup's CPU quota where there is one, else the affinity mask -- 32 at most.
+// K2R_HOST_THREADS overrides.
+int host_threads() {
+    static const int n = [] {
+        if (const char* e = std::getenv("K2R_HOST_THREADS")) {
+            const int v = std::atoi(e);
+            if (v >= 1) return std::min(v, 64);
+        }
+        int c = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) c = CPU_COUNT(&set);
+        if (c <= 0) c = (int)std::thread::hardware_concurrency();
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+            long long quota = 0, period = 0;
+            if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                c = std::min<int>(c, (int)std::max<long long>(1, (quota + period - 1) / period));
+            std::fclose(f);
+        }
+        return std::max(1, std::min(c + c / 2, 32));
+    }();
+    return n;
+}
 
 struct PinRing {
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t slot_ev[kDownSlots] = {nullptr, nullptr, nullptr, nullptr};
     bool busy[2] = {false, false};
     hipStream_t stream = nullptr;
     bool ok = false;
@@ -875,14 +909,16 @@ struct PinRing {
         if (ok) return true;
         for (int i = 0; i < 2; i++) {
             // page-locked if the system allows it; otherwise ordinary memory (the copies then stage inside the runtime)
-            if (hipHostMalloc(&buf[i], kPinBytes, hipHostMallocDefault) != hipSuccess) {
+            if (!buf[i] && hipHostMalloc(&buf[i], kPinBytes, hipHostMallocDefault) != hipSuccess) {
                 (void)hipGetLastError();
                 buf[i] = std::malloc(kPinBytes);
                 if (!buf[i]) return false;
             }
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+            if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
         }
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int i = 0; i < kDownSlots; i++)
+            if (!slot_ev[i] && hipEventCreateWithFlags(&slot_ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
         ok = true;
         return true;
     }
@@ -891,16 +927,17 @@ struct PinRing {
         busy[b] = false;
         return true;
     }
+    uint8_t* slot(int s) const { return (uint8_t*)buf[s / (kDownSlots / 2)] + (size_t)(s % (kDownSlots / 2)) * kSlotBytes; }
 };
 PinRing& pin_ring() {
     static PinRing r;
     return r;
 }
 
-// runs f(0..n) on up to kPackThreads threads
+// runs f(0..n) on up to host_threads() threads
 template <class F>
 void parallel_for(size_t n, F&& f) {
-    const size_t nt = std::min<size_t>(kPackThreads, n);
+    const size_t nt = std::min<size_t>((size_t)host_threads(), n);
     if (nt <= 1) {
         for (size_t i = 0; i < n; i++) f(i);
         return;
@@ -1047,6 +1084,7 @@ static int build_group(const dcdf_tile_desc* tiles, size_t n, int k, int mem, dc
 
 namespace k2r {
 void host_parallel_for(size_t n, const std::function<void(size_t)>& f) { parallel_for(n, f); }
+int host_thread_count() { return host_threads(); }
 
 int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint64_t)>& dst, const std::function<void(size_t)>& landed) {
     {
@@ -1060,72 +1098,105 @@ int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint6
     PinRing& ring = pin_ring();
     std::lock_guard<std::mutex> ring_lock(ring.mu);
     if (!ring.init()) return DCDF_ERR_NOMEM;
+    // The copy engine fills one 32 MB slot of the pinned ring after the other (one asynchronous copy per object, one event per slot);
+    // worker threads take the objects of a slot as soon as its event has fired -- destination from `dst`, memcpy, `landed` (the
+    // caller's hash) -- and a slot is filled again when its last object has been taken out.  Copy, unpacking and hashing of
+    // different slots overlap; nothing waits for a whole buffer.
+    struct Task {
+        size_t tile;
+        int slot;
+        uint64_t off;
+    };
+    std::mutex mu;
+    std::condition_variable cv_task, cv_slot;
+    std::deque<Task> tasks;
+    int outstanding[kDownSlots] = {0, 0, 0, 0};
+    bool closing = false;
+    std::atomic<bool> nomem{false}, hipfail{false};
+    auto worker = [&] {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_task.wait(lk, [&] { return !tasks.empty() || closing; });
+                if (tasks.empty()) return;
+                t = tasks.front();
+                tasks.pop_front();
+            }
+            if (hipEventSynchronize(ring.slot_ev[t.slot]) != hipSuccess) hipfail = true;
+            else if (uint8_t* d = dst(t.tile, lens[t.tile])) {
+                std::memcpy(d, ring.slot(t.slot) + t.off, lens[t.tile]);
+                if (landed) landed(t.tile);
+            } else nomem = true;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--outstanding[t.slot] == 0) cv_slot.notify_all();
+            }
+        }
+    };
+    size_t n_big = 0;
+    for (size_t i = 0; i < n; i++) n_big += lens[i] != 0 && lens[i] <= kSlotBytes;
+    std::vector<std::thread> pool;
+    for (size_t t = 0, nt = std::min<size_t>((size_t)host_threads(), n_big); t < nt; t++) pool.emplace_back(worker);
+    // Every exit leaves the ring as the next caller expects it: workers gone, no copy still landing in a pinned buffer.
+    auto finish = [&](int rc) -> int {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closing = true;
+        }
+        cv_task.notify_all();
+        for (auto& t : pool) t.join();
+        if (rc != DCDF_OK || hipfail) (void)hipStreamSynchronize(ring.stream);
+        if (rc != DCDF_OK) return rc;
+        if (hipfail) return DCDF_ERR_NO_DEVICE;
+        return nomem ? DCDF_ERR_NOMEM : DCDF_OK;
+    };
+#define K2R_HIP_Q(call)                                                 \
+    do {                                                                \
+        hipError_t _e = (call);                                         \
+        if (_e != hipSuccess) return finish(k2r::map_hip_error(_e));    \
+    } while (0)
     size_t i = 0;
     int fill = 0;
-    std::vector<size_t> pend[2];
-    std::vector<uint64_t> pend_off[2];
-    bool failed = false;
-    auto drain = [&](int b) -> bool {
-        if (!ring.wait(b)) return false;
-        const uint8_t* pb = (const uint8_t*)ring.buf[b];
-        std::atomic<bool> bad{false};
-        parallel_for(pend[b].size(), [&](size_t q) {
-            const size_t ti = pend[b][q];
-            uint8_t* d = dst(ti, lens[ti]);
-            if (!d) bad = true;
-            else {
-                std::memcpy(d, pb + pend_off[b][q], lens[ti]);
-                if (landed) landed(ti);
-            }
-        });
-        pend[b].clear();
-        pend_off[b].clear();
-        failed = failed || bad;
-        return true;
-    };
-    // Every early exit leaves the ring as the next caller expects it: no copy still landing in a pinned buffer, no busy mark.
-    auto quiesce = [&](int rc) -> int {
-        (void)hipStreamSynchronize(ring.stream);
-        ring.busy[0] = ring.busy[1] = false;
-        return rc;
-    };
-#define K2R_HIP_Q(call)                                                  \
-    do {                                                                 \
-        hipError_t _e = (call);                                          \
-        if (_e != hipSuccess) return quiesce(k2r::map_hip_error(_e));    \
-    } while (0)
     while (i < n) {
         if (lens[i] == 0) {
             i++;
             continue;
         }
-        if (lens[i] > kPinBytes) {  // oversize result: plain copy
+        if (lens[i] > kSlotBytes) {  // oversize result: plain copy
             uint8_t* d = dst(i, lens[i]);
-            if (!d) return quiesce(DCDF_ERR_NOMEM);
+            if (!d) return finish(DCDF_ERR_NOMEM);
             K2R_HIP_Q(hipMemcpy(d, e->args[i].out, lens[i], hipMemcpyDeviceToHost));
             if (landed) landed(i);
             i++;
             continue;
         }
-        const int b = fill & 1;
-        if (!drain(b)) return quiesce(DCDF_ERR_NO_DEVICE);
+        const int s = fill % kDownSlots;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_slot.wait(lk, [&] { return outstanding[s] == 0; });
+        }
+        std::vector<Task> batch;
         uint64_t used = 0;
-        while (i < n && (lens[i] == 0 || (lens[i] <= kPinBytes && used + lens[i] <= kPinBytes))) {
+        while (i < n && (lens[i] == 0 || (lens[i] <= kSlotBytes && used + lens[i] <= kSlotBytes))) {
             if (lens[i]) {
-                K2R_HIP_Q(hipMemcpyAsync((uint8_t*)ring.buf[b] + used, e->args[i].out, lens[i], hipMemcpyDeviceToHost, ring.stream));
-                pend[b].push_back(i);
-                pend_off[b].push_back(used);
+                K2R_HIP_Q(hipMemcpyAsync(ring.slot(s) + used, e->args[i].out, lens[i], hipMemcpyDeviceToHost, ring.stream));
+                batch.push_back(Task{i, s, used});
                 used += (lens[i] + 63) & ~63ull;
             }
             i++;
         }
-        K2R_HIP_Q(hipEventRecord(ring.ev[b], ring.stream));
-        ring.busy[b] = true;
+        K2R_HIP_Q(hipEventRecord(ring.slot_ev[s], ring.stream));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            outstanding[s] = (int)batch.size();
+            for (const Task& t : batch) tasks.push_back(t);
+        }
+        cv_task.notify_all();
         fill++;
     }
 #undef K2R_HIP_Q
-    if (!drain(0) || !drain(1)) return quiesce(DCDF_ERR_NO_DEVICE);
-    return failed ? DCDF_ERR_NOMEM : DCDF_OK;
+    return finish(DCDF_OK);
 }
 }  // namespace k2r
 

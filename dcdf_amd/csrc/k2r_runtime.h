@@ -36,20 +36,26 @@ struct Runtime {
     static Runtime& get();  // lazily initialised; ok == false when no usable device
 };
 
-// A few large device blocks kept between calls.  hipMalloc / hipFree of gigabytes cost tens of milliseconds each (and hipFree
-// synchronises the device); a caller that appends slice after slice (Variable::append -> dcdf_superchunk_build) asks for the
-// same sizes again and again.  Only the big, write-before-read buffers of a session go through it (output slots, packing and
-// scratch areas: DevBuf::alloc_pooled); contents are never assumed.  K2R_POOL=0 disables it.  The pool is never destroyed: HIP
-// calls at static-destruction time are not safe.
+// Device blocks kept between calls.  hipMalloc / hipFree of gigabytes cost tens of milliseconds each, the dozen small tables of a
+// session a few hundred microseconds each -- and hipFree waits for everything queued on the device, uploads of the NEXT band
+// included (the banded superchunk assembly lost more to that than it gained from the overlap).  A caller that appends slice after
+// slice (Variable::append -> dcdf_superchunk_build) asks for the same sizes again and again, so released blocks are parked: large
+// ones (>= 16 MB) are handed out again for requests of 2/3 .. 1 of their size, small ones by power-of-two size class.  Contents are
+// never assumed.  A parked block carries an event recorded on the null stream when it was released -- behind everything queued
+// on the session streams at that moment -- and whoever takes it waits for that event first: a release never blocks the host, and
+// a block is idle before it is used again, error paths included.  K2R_POOL=0 disables it.  The pool is never destroyed: HIP calls
+// at static-destruction time are not safe.
 struct DevPool {
     struct Blk {
         void* p;
         size_t n;
+        hipEvent_t ev;
     };
     std::mutex mu;
-    std::vector<Blk> blocks;  // oldest first
-    size_t held = 0;
-    static constexpr size_t kMinBytes = 16u << 20, kMaxHeld = 12ull << 30, kMaxBlocks = 12;
+    std::vector<Blk> large, small;  // oldest first
+    size_t held_large = 0, held_small = 0;
+    static constexpr size_t kMinBytes = 16u << 20, kMaxHeld = 12ull << 30, kMaxBlocks = 32;
+    static constexpr size_t kMaxSmallHeld = 256u << 20, kMaxSmallBlocks = 512;
     static DevPool& get() {
         static DevPool* pool = new DevPool();
         return *pool;
@@ -61,56 +67,133 @@ struct DevPool {
         }();
         return on;
     }
-    void* take(size_t n, size_t* got) {  // the smallest kept block of n .. 1.5 n bytes
-        std::lock_guard<std::mutex> lk(mu);
-        size_t best = blocks.size();
-        for (size_t i = 0; i < blocks.size(); i++)
-            if (blocks[i].n >= n && blocks[i].n <= n + n / 2 && (best == blocks.size() || blocks[i].n < blocks[best].n)) best = i;
-        if (best == blocks.size()) return nullptr;
-        void* p = blocks[best].p;
-        *got = blocks[best].n;
-        held -= blocks[best].n;
-        blocks.erase(blocks.begin() + (long)best);
-        return p;
+    static size_t size_class(size_t n) {  // what a request of n bytes allocates
+        if (n >= kMinBytes) return n;
+        size_t c = 256;
+        while (c < n) c <<= 1;
+        return c;
+    }
+    void* take(size_t n, size_t* got) {  // large: the smallest kept block of n .. 1.5 n bytes; small: one of the request's class
+        Blk b{nullptr, 0, nullptr};
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (n >= kMinBytes) {
+                size_t best = large.size();
+                for (size_t i = 0; i < large.size(); i++)
+                    if (large[i].n >= n && large[i].n <= n + n / 2 && (best == large.size() || large[i].n < large[best].n)) best = i;
+                if (best == large.size()) return nullptr;
+                b = large[best];
+                held_large -= b.n;
+                large.erase(large.begin() + (long)best);
+            } else {
+                const size_t c = size_class(n);
+                size_t at = small.size();
+                for (size_t i = small.size(); i-- > 0;)
+                    if (small[i].n == c) {
+                        at = i;
+                        break;
+                    }
+                if (at == small.size()) return nullptr;
+                b = small[at];
+                held_small -= b.n;
+                small.erase(small.begin() + (long)at);
+            }
+        }
+        if (b.ev) {
+            if (hipEventSynchronize(b.ev) != hipSuccess) (void)hipDeviceSynchronize();
+            (void)hipEventDestroy(b.ev);
+        }
+        *got = b.n;
+        return b.p;
+    }
+    static void drop(const Blk& b) {
+        if (b.ev) (void)hipEventDestroy(b.ev);
+        (void)hipFree(b.p);  // (waits for the device by itself)
     }
     // every kept block back to the driver (out of memory elsewhere in the process; dcdf_device_pool_trim)
     size_t drain() {
         std::vector<Blk> all;
         {
             std::lock_guard<std::mutex> lk(mu);
-            all.swap(blocks);
-            held = 0;
+            all.swap(large);
+            all.insert(all.end(), small.begin(), small.end());
+            small.clear();
+            held_large = held_small = 0;
         }
         size_t freed = 0;
         for (const Blk& b : all) {
-            (void)hipFree(b.p);
+            drop(b);
             freed += b.n;
         }
         return freed;
     }
     void give(void* p, size_t n) {
-        // hipFree used to order the release behind everything queued on the device; a block parked here may be handed to
-        // another host thread at once, so it must be just as idle (error paths release with copies or kernels still queued)
-        (void)hipDeviceSynchronize();
-        std::vector<Blk> drop;
+        Blk b{p, n, nullptr};
+        if (hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(b.ev, nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            if (b.ev) (void)hipEventDestroy(b.ev);
+            b.ev = nullptr;
+            (void)hipDeviceSynchronize();  // (no event to wait for later: idle now)
+        }
+        std::vector<Blk> out;
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (n < kMinBytes || n > kMaxHeld) drop.push_back(Blk{p, n});
-            else {
-                blocks.push_back(Blk{p, n});
-                held += n;
-                while (held > kMaxHeld || blocks.size() > kMaxBlocks) {
-                    drop.push_back(blocks.front());
-                    held -= blocks.front().n;
-                    blocks.erase(blocks.begin());
+            if (n >= kMinBytes) {
+                if (n > kMaxHeld) out.push_back(b);
+                else {
+                    large.push_back(b);
+                    held_large += n;
+                    while (held_large > kMaxHeld || large.size() > kMaxBlocks) {
+                        out.push_back(large.front());
+                        held_large -= large.front().n;
+                        large.erase(large.begin());
+                    }
+                }
+            } else {
+                small.push_back(b);
+                held_small += n;
+                while (held_small > kMaxSmallHeld || small.size() > kMaxSmallBlocks) {
+                    out.push_back(small.front());
+                    held_small -= small.front().n;
+                    small.erase(small.begin());
                 }
             }
         }
-        for (const Blk& b : drop) (void)hipFree(b.p);
+        for (const Blk& d : out) drop(d);
     }
 };
 
-// RAII device buffer
+// HIP streams kept between calls: creating one costs a millisecond and destroying one stalls every other thread's HIP calls for
+// several (measured in the banded superchunk assembly, where a stream died while other threads were mid-band).  A stream handed
+// back must be idle.  Never destroyed.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> blocking, nonblocking;
+    static StreamPool& get() {
+        static StreamPool* sp = new StreamPool();
+        return *sp;
+    }
+    hipError_t take(bool nonblock, hipStream_t* out) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = nonblock ? nonblocking : blocking;
+            if (!v.empty()) {
+                *out = v.back();
+                v.pop_back();
+                return hipSuccess;
+            }
+        }
+        return hipStreamCreateWithFlags(out, nonblock ? hipStreamNonBlocking : hipStreamDefault);
+    }
+    void give(bool nonblock, hipStream_t s) {
+        if (!s) return;
+        (void)hipStreamSynchronize(s);
+        std::lock_guard<std::mutex> lk(mu);
+        (nonblock ? nonblocking : blocking).push_back(s);
+    }
+};
+
+// RAII device buffer (from the pool above; `bytes` may come back larger than asked)
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -131,20 +214,8 @@ struct DevBuf {
     hipError_t alloc(size_t n) {
         release();
         if (n == 0) n = 16;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess && DevPool::enabled() && DevPool::get().drain() > 0) {  // memory idling in the pool: retry once
-            (void)hipGetLastError();
-            e = hipMalloc(&p, n);
-        }
-        if (e == hipSuccess) bytes = n;
-        else p = nullptr;
-        return e;
-    }
-    // for large buffers that are written before they are read (see DevPool); `bytes` may come back larger than asked
-    hipError_t alloc_pooled(size_t n) {
-        release();
-        if (n == 0) n = 16;
-        if (DevPool::enabled() && n >= DevPool::kMinBytes) {
+        const bool pool = DevPool::enabled();
+        if (pool) {
             size_t got = 0;
             if (void* q = DevPool::get().take(n, &got)) {
                 p = q;
@@ -152,28 +223,22 @@ struct DevBuf {
                 pooled = true;
                 return hipSuccess;
             }
+            n = DevPool::size_class(n);
         }
         hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess && pool && DevPool::get().drain() > 0) {  // memory idling in the pool: give it back and try once more
+            (void)hipGetLastError();
+            e = hipMalloc(&p, n);
+        }
         if (e == hipSuccess) {
             bytes = n;
-            pooled = DevPool::enabled() && n >= DevPool::kMinBytes;
+            pooled = pool;
         } else {
             p = nullptr;
-            if (DevPool::enabled()) {  // out of memory with blocks parked in the pool: give them back and try once more
-                if (DevPool::get().drain() > 0) {
-                    (void)hipGetLastError();
-                    e = hipMalloc(&p, n);
-                    if (e == hipSuccess) {
-                        bytes = n;
-                        pooled = n >= DevPool::kMinBytes;
-                    } else {
-                        p = nullptr;
-                    }
-                }
-            }
         }
         return e;
     }
+    hipError_t alloc_pooled(size_t n) { return alloc(n); }
     template <class T>
     T* as() const { return (T*)p; }
 };
@@ -188,6 +253,8 @@ int encoder_download(dcdf_encoder* e, const std::function<uint8_t*(size_t, uint6
                      const std::function<void(size_t)>& landed = nullptr);
 // runs f(0..n) on a few host threads
 void host_parallel_for(size_t n, const std::function<void(size_t)>& f);
+// how many: see host_threads() in k2r_capi_encode.hip (K2R_HOST_THREADS overrides)
+int host_thread_count();
 
 inline int map_status(int32_t st) {
     switch (st) {

@@ -27,6 +27,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <map>
 #include <memory>
 #include <string>
@@ -227,7 +230,160 @@ struct StepTimer {  // K2R_SC_TIMING=1: wall time of the assembly's steps on std
         t = n;
     }
 };
-int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size_t n_levels, Level* out) {
+// K2R_SC_TIMING: a timeline of the banded assembly on stderr (ms since the first mark of the process)
+void trace(const char* what, long a = -1) {
+    static const bool on = std::getenv("K2R_SC_TIMING") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "k2r-sc-trace %9.2f ms  %s %ld\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what, a);
+}
+
+// A host view on its way to HBM, band of rows after band of rows, on a thread of its own: the assembly below starts on the tiles of
+// a band as soon as its rows (of every instant) have landed, and the bands behind it keep the host-to-device link busy meanwhile.
+// Dense rows and row-pitched views are copied straight from the caller's array (the runtime page-locks pageable memory on the
+// way and reaches the link's rate; staging them through page-locked buffers with host threads was measured slower: the copies
+// take the cores the download's hashing needs); other strides are gathered row by row into a staging vector first.
+struct Upload {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t rows_ready = 0, band_rows = 0;
+    int rc = DCDF_OK;
+    struct Piece {
+        uint32_t t, r0, r1, band;
+    };
+    std::vector<Piece> pieces;            // band after band, instant after instant
+    std::vector<uint32_t> band_end;       // rows uploaded once bands 0..b are complete
+    std::vector<uint32_t> band_left;      // pieces of band b still to land (under mu)
+    uint32_t bands_done = 0;
+    std::atomic<size_t> next{0};
+    int wait_rows(uint32_t upto) {  // rows [0, upto) of every instant are in HBM (or the upload failed)
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return rows_ready >= upto || rc != DCDF_OK; });
+        return rc;
+    }
+    void landed(uint32_t band) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            band_left[band]--;
+            while (bands_done < band_left.size() && band_left[bands_done] == 0) {
+                rows_ready = band_end[bands_done++];
+                trace("band uploaded", (long)bands_done - 1);
+            }
+        }
+        cv.notify_all();
+    }
+    void fail(int code) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc == DCDF_OK) rc = code;
+        }
+        cv.notify_all();
+    }
+    void* registered = nullptr;
+    int start(const dcdf_tile_desc& src, uint8_t* dst, uint32_t rows_per_band) {
+        const uint64_t T = src.instants, R = src.rows;
+        // Page-lock the caller's array for the duration of the call when the view is dense enough for that to pay: the pieces below
+        // then go out as plain asynchronous DMA (a piece of pageable memory is locked and unlocked by the runtime per copy: 32 GB/s
+        // measured against 56 for one large copy).  Not possible (read-only mappings, already registered, ...): pageable copies.
+        if (src.stride_c == 1 && src.stride_r >= (int64_t)src.cols && src.stride_t >= src.stride_r * (int64_t)R &&
+            std::getenv("K2R_NO_HOST_REGISTER") == nullptr) {
+            const size_t es = esize(src.dtype);
+            const size_t span = (size_t)(((int64_t)(T - 1) * src.stride_t + (int64_t)(R - 1) * src.stride_r + (int64_t)src.cols) * (int64_t)es);
+            const size_t dense = (size_t)(T * R * src.cols) * es;
+            if (span <= dense + dense / 4 && dense >= (64u << 20)) {
+                trace("upload: registering the host view, MB", (long)(span >> 20));
+                if (hipHostRegister((void*)src.base, span, hipHostRegisterDefault) == hipSuccess) registered = (void*)src.base;
+                else (void)hipGetLastError();
+                trace("upload: registered", registered ? 1 : 0);
+            }
+        }
+        for (uint64_t b0 = 0, band = 0; b0 < R; b0 += rows_per_band, band++) {
+            const uint64_t b1 = std::min<uint64_t>(b0 + rows_per_band, R);
+            for (uint64_t t = 0; t < T; t++) pieces.push_back(Piece{(uint32_t)t, (uint32_t)b0, (uint32_t)b1, (uint32_t)band});
+            band_end.push_back((uint32_t)b1);
+            band_left.push_back((uint32_t)T);
+        }
+        // (one thread issues the pieces; more of them were measured no faster, page-locked or not)
+        size_t nt = 1;
+        if (const char* e = std::getenv("K2R_UP_THREADS")) nt = (size_t)std::max(1, std::min(16, std::atoi(e)));
+        nt = std::min(nt, pieces.size());
+        const int device = Runtime::get().device;
+        for (size_t j = 0; j < nt; j++)
+            th.emplace_back([this, src, dst, device] {
+                const size_t es = esize(src.dtype);
+                const uint64_t R = src.rows, Cc = src.cols;
+                const int64_t st = src.stride_t, sr = src.stride_r, sc = src.stride_c;
+                const uint8_t* const base = (const uint8_t*)src.base;
+                hipStream_t stream = nullptr;
+                hipError_t he = hipSetDevice(device);
+                if (he == hipSuccess) he = StreamPool::get().take(true, &stream);
+                std::vector<uint8_t> gather;
+                // at most two pieces of this thread in flight: the session tables and the (min, max) results of the bands already
+                // here travel on the same copy engines, and behind a whole band of queued pieces they waited 5 ms per small copy
+                hipEvent_t ev[2] = {nullptr, nullptr};
+                int64_t pending[2] = {-1, -1};
+                for (int i = 0; i < 2 && he == hipSuccess; i++) he = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+                auto retire = [&](int i) {
+                    if (pending[i] < 0) return;
+                    if (he == hipSuccess) he = hipEventSynchronize(ev[i]);
+                    if (he == hipSuccess) landed(pieces[(size_t)pending[i]].band);
+                    pending[i] = -1;
+                };
+                for (size_t k = 0; he == hipSuccess; k++) {
+                    const size_t p = next.fetch_add(1);
+                    if (p >= pieces.size()) break;
+                    const int slot = (int)(k & 1);
+                    retire(slot);
+                    if (he != hipSuccess) break;
+                    const Piece& pc = pieces[p];
+                    const uint64_t nr = pc.r1 - pc.r0;
+                    uint8_t* const d = dst + (size_t)(((uint64_t)pc.t * R + pc.r0) * Cc) * es;
+                    const uint8_t* const from = base + ((int64_t)pc.t * st + (int64_t)pc.r0 * sr) * (int64_t)es;
+                    if (sc == 1 && sr == (int64_t)Cc) {
+                        he = hipMemcpyAsync(d, from, (size_t)(nr * Cc) * es, hipMemcpyHostToDevice, stream);  // dense rows
+                    } else if (sc == 1 && sr > (int64_t)Cc) {
+                        // a row pitch (a cropped window of a larger array): a 2-D copy does the gathering
+                        he = hipMemcpy2DAsync(d, (size_t)Cc * es, from, (size_t)sr * es, (size_t)Cc * es, (size_t)nr, hipMemcpyHostToDevice, stream);
+                    } else {
+                        // other strides (transposed / reversed / stepped views): gathered row by row
+                        gather.resize((size_t)(nr * Cc) * es);
+                        uint8_t* g = gather.data();
+                        for (uint64_t r = 0; r < nr; r++) {
+                            const uint8_t* row = from + (int64_t)r * sr * (int64_t)es;
+                            if (es == 4)
+                                for (uint64_t c = 0; c < Cc; c++, g += 4) *(uint32_t*)g = *(const uint32_t*)(row + (int64_t)c * sc * 4);
+                            else
+                                for (uint64_t c = 0; c < Cc; c++, g += 8) *(uint64_t*)g = *(const uint64_t*)(row + (int64_t)c * sc * 8);
+                        }
+                        he = hipMemcpyAsync(d, gather.data(), gather.size(), hipMemcpyHostToDevice, stream);
+                        if (he == hipSuccess) he = hipStreamSynchronize(stream);  // (the staging is reused)
+                    }
+                    if (he == hipSuccess) he = hipEventRecord(ev[slot], stream);
+                    if (he == hipSuccess) pending[slot] = (int64_t)p;
+                }
+                retire(0);
+                retire(1);
+                StreamPool::get().give(true, stream);
+                for (int i = 0; i < 2; i++)
+                    if (ev[i]) (void)hipEventDestroy(ev[i]);
+                if (he != hipSuccess) fail(k2r::map_hip_error(he));
+            });
+        return DCDF_OK;
+    }
+    void join() {
+        for (auto& t : th)
+            if (t.joinable()) t.join();
+        if (registered) {
+            (void)hipHostUnregister(registered);
+            registered = nullptr;
+            trace("upload: unregistered");
+        }
+    }
+    ~Upload() { join(); }
+};
+
+int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size_t n_levels, Level* out, Upload* up = nullptr) {
     StepTimer tm;
     const int k = cx.k;
     const uint32_t instants = buf.instants, rows = buf.rows, cols = buf.cols;
@@ -248,8 +404,6 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
     // ---- the grid (superchunk.rs:127-142) and its per-instant (min, max) on the device ----
     std::vector<dcdf_tile_desc> tiles(n_tiles);
     std::vector<char> inside(n_tiles, 0);
-    std::vector<MinMaxTile> mt;
-    std::vector<size_t> mt_tile;
     for (uint64_t row = 0; row < subsidelen; row++)
         for (uint64_t col = 0; col < subsidelen; col++) {
             const size_t i = (size_t)(row * subsidelen + col);
@@ -262,30 +416,8 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             t.cols = (uint32_t)(right - left);
             tiles[i] = t;
             inside[i] = 1;
-            mt.push_back(MinMaxTile{t.base, t.stride_t, t.stride_r, t.stride_c, t.rows, t.cols});
-            mt_tile.push_back(i);
         }
     std::vector<int64_t> mm(2ull * n_tiles * instants, 0);  // [tile][instant][2]
-    if (!mt.empty()) {
-        DevBuf d_mt, d_out, d_st;
-        K2R_HIP(d_mt.alloc(mt.size() * sizeof(MinMaxTile)));
-        K2R_HIP(d_out.alloc(mt.size() * instants * 16ull));
-        K2R_HIP(d_st.alloc(4));
-        K2R_HIP(hipMemcpy(d_mt.p, mt.data(), mt.size() * sizeof(MinMaxTile), hipMemcpyHostToDevice));
-        K2R_HIP(hipMemset(d_st.p, 0, 4));
-        hipLaunchKernelGGL(k_tile_minmax, dim3((uint32_t)(mt.size() * instants)), dim3(256), 0, 0, d_mt.as<MinMaxTile>(), instants, buf.dtype,
-                           (uint32_t)buf.fractional_bits, (uint32_t)buf.round, d_out.as<int64_t>(), d_st.as<int32_t>());
-        K2R_HIP(hipGetLastError());
-        std::vector<int64_t> got(mt.size() * instants * 2ull);
-        K2R_HIP(hipMemcpy(got.data(), d_out.p, got.size() * 8, hipMemcpyDeviceToHost));
-        int32_t st = 0;
-        K2R_HIP(hipMemcpy(&st, d_st.p, 4, hipMemcpyDeviceToHost));
-        if (st != 0) return map_status(st);  // to_fixed panics (fixed.rs:39-70)
-        for (size_t q = 0; q < mt.size(); q++)
-            std::memcpy(&mm[2ull * mt_tile[q] * instants], &got[2ull * q * instants], 16ull * instants);
-    }
-    tm.lap("tile min/max");
-    // ---- elision, sub-builds (superchunk.rs:144-181) ----
     std::vector<char> elided(n_tiles, 1);
     struct Sub {
         size_t tile;
@@ -302,99 +434,22 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
         }
     };
     std::vector<Sub> subs;
-    SubsGuard subs_guard{subs};
-    std::vector<dcdf_tile_desc> chunk_descs;
-    std::vector<size_t> chunk_sub;
-    auto can_elide_tile = [&](size_t i) {
-        for (uint32_t t = 0; t < instants; t++)
-            if (mm[2ull * (i * instants + t)] != mm[2ull * (i * instants + t) + 1]) return false;
-        return true;
+    subs.reserve(n_tiles);  // (the download thread fills entries while later bands append theirs: no reallocation)
+    std::vector<std::string> chunk_cid(n_tiles);  // CIDs of the sub-chunk objects, by index into subs
+    // ---- the sessions' results come to the host on a thread of their own when the level is assembled in bands ----
+    struct Job {
+        dcdf_encoder* e = nullptr;
+        std::vector<size_t> chunk_sub;  // session tile -> index into subs
     };
-    // fractional bits of every float tile that will be built (fixed.rs:96-159), for the whole level at once
-    std::vector<size_t> frac_of(n_tiles, 0);
-    std::vector<int32_t> frac_rnd, frac_bits, frac_st;
-    if (buf.dtype == DCDF_F32 || buf.dtype == DCDF_F64) {
-        std::vector<dcdf_tile_desc> ft;
-        for (size_t i = 0; i < n_tiles; i++)
-            if (inside[i] && !can_elide_tile(i)) {
-                frac_of[i] = ft.size();
-                ft.push_back(tiles[i]);
-            }
-        frac_rnd.resize(ft.size());
-        frac_bits.resize(ft.size());
-        frac_st.resize(ft.size());
-        if (!ft.empty()) {
-            const int rc = suggest_fraction_batch(ft.data(), ft.size(), frac_rnd.data(), frac_bits.data(), frac_st.data());
-            if (rc != DCDF_OK) return rc;
-        }
-    }
-    for (size_t i = 0; i < n_tiles; i++) {
-        if (!inside[i]) continue;
-        bool can_elide = true;
-        for (uint32_t t = 0; t < instants && can_elide; t++) can_elide = mm[2ull * (i * instants + t)] == mm[2ull * (i * instants + t) + 1];
-        if (can_elide) continue;
-        elided[i] = 0;
-        dcdf_tile_desc t = tiles[i];
-        bool build_subchunk = at_bottom;
-        if (!at_bottom) build_subchunk = levels_needed(std::max(t.rows, t.cols), k) <= sublevels[0];  // superchunk.rs:155-165
-        if (t.dtype == DCDF_F32 || t.dtype == DCDF_F64) {  // sub_buffer.compute_fractional_bits() (mmbuffer.rs:596-613)
-            const size_t fi = frac_of[i];  // (all tiles of the level in two launches, before this loop)
-            if (frac_st[fi] != DCDF_OK) return frac_st[fi];
-            int32_t bits = frac_bits[fi];
-            if (t.round) bits = std::min<int32_t>(bits, t.fractional_bits);
-            else if (frac_rnd[fi]) return DCDF_ERR_PRECISION;  // panic!("loss of precision")
-            t.fractional_bits = (uint8_t)bits;
-        }
-        Sub s{};
-        s.tile = i;
-        s.chunk = build_subchunk;
-        if (build_subchunk) {
-            chunk_descs.push_back(t);
-            chunk_sub.push_back(subs.size());
-        } else {
-            Level sub;
-            const int rc = build_level(cx, t, sublevels, n_sub, &sub);
-            if (rc != DCDF_OK) return rc;
-            s.obj = sub.node;
-            s.size = sub.size_self + 1;  // MMStruct3::size (mmstruct.rs:187-197)
-            s.snapshots = sub.snapshots;
-            s.logs = sub.logs;
-        }
-        subs.push_back(std::move(s));
-    }
-    std::vector<std::string> chunk_cid(subs.size());  // CIDs of the sub-chunk objects, hashed where their bytes lie (HBM)
-    if (!chunk_descs.empty()) {
-        // every Chunk::build of this level in ONE launch (superchunk.rs:169) on a device-resident session: the objects' SHA-256
-        // is taken on the device from the encoder's own buffers (dcdf_encoder_object_sha256) and the bytes come to the host in
-        // one packed copy (dcdf_encoder_gather) -- no per-tile copies, no re-upload for hashing
-        struct EncGuard {
-            dcdf_encoder* e = nullptr;
-            ~EncGuard() {
-                if (e) dcdf_encoder_destroy(e);
-            }
-        } g;
-        tm.lap("fractional bits, tiling");
-        int rc = dcdf_encoder_create(chunk_descs.data(), chunk_descs.size(), k, 0, &g.e);
-        if (rc != DCDF_OK) return rc;
-        tm.lap("encoder_create");
-        rc = dcdf_encoder_run(g.e, nullptr);
-        if (rc != DCDF_OK) return rc;
-        tm.lap("encoder_run");
-        const size_t nc = chunk_descs.size();
-        for (size_t q = 0; q < nc; q++) {
-            int32_t st = 0;
-            rc = dcdf_encoder_result(g.e, q, &st, nullptr, nullptr, nullptr, nullptr);
-            if (rc != DCDF_OK) return rc;
-            if (st != DCDF_OK) return st;
-        }
-        // the bytes come to the host through the pinned double buffer and land, framed, in their final objects: header + tag
-        // written, then the chunk bytes copied in by the download's worker threads, which hash the object there and then
-        // (its CID: SHA-256 on the host while the next buffer is in flight -- k2r_sha256_host.h)
-        const std::string hd = header(2) + std::string(1, (char)4);  // NODE_MMSTRUCT3, NODE_SUBCHUNK (mmstruct.rs:215-218)
-        rc = k2r::encoder_download(
-            g.e,
+    const std::string hd = header(2) + std::string(1, (char)4);  // NODE_MMSTRUCT3, NODE_SUBCHUNK (mmstruct.rs:215-218)
+    // the bytes come to the host through the pinned ring and land, framed, in their final objects: header + tag written, then the
+    // chunk bytes copied in by the download's worker threads, which hash the object there and then (its CID: SHA-256 on the host
+    // while the next slot is in flight -- k2r_sha256_host.h)
+    auto fetch = [&](Job& j) -> int {
+        int rc = k2r::encoder_download(
+            j.e,
             [&](size_t q, uint64_t len) -> uint8_t* {
-                Blob& o = subs[chunk_sub[q]].blob;
+                Blob& o = subs[j.chunk_sub[q]].blob;
                 o.n = hd.size() + len;
                 o.p = (uint8_t*)std::malloc(o.n);
                 if (!o.p) return nullptr;
@@ -402,22 +457,206 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
                 return o.p + hd.size();
             },
             [&](size_t q) {
-                const Blob& o = subs[chunk_sub[q]].blob;
-                chunk_cid[chunk_sub[q]] = cid_of(o.p, o.n);
+                const Blob& o = subs[j.chunk_sub[q]].blob;
+                chunk_cid[j.chunk_sub[q]] = cid_of(o.p, o.n);
             });
-        if (rc != DCDF_OK) return rc;
-        tm.lap("download + framing + sha256");
-        for (size_t q = 0; q < nc; q++) {
+        for (size_t q = 0; rc == DCDF_OK && q < j.chunk_sub.size(); q++) {
             uint64_t len = 0;
             uint32_t ns = 0, nl = 0;
             int32_t st = 0;
-            (void)dcdf_encoder_result(g.e, q, &st, &len, &ns, &nl, nullptr);
-            Sub& s = subs[chunk_sub[q]];
-            s.size = len + 1;
-            s.snapshots = ns;
-            s.logs = nl;
+            (void)dcdf_encoder_result(j.e, q, &st, &len, &ns, &nl, nullptr);
+            Sub& sb = subs[j.chunk_sub[q]];
+            sb.size = len + 1;
+            sb.snapshots = ns;
+            sb.logs = nl;
+        }
+        dcdf_encoder_destroy(j.e);
+        j.e = nullptr;
+        return rc;
+    };
+    struct Fetcher {  // jobs in, first failure out
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<Job*> q;
+        bool closing = false;
+        int rc = DCDF_OK;
+        std::vector<std::unique_ptr<Job>> jobs;
+        int close() {  // after the last push: wait for the queue to drain
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                closing = true;
+            }
+            cv.notify_all();
+            if (th.joinable()) th.join();
+            return rc;
+        }
+        ~Fetcher() {
+            (void)close();
+            for (auto& j : jobs)
+                if (j->e) dcdf_encoder_destroy(j->e);
+        }
+    };
+    SubsGuard subs_guard{subs};  // (declared before the fetcher: its thread is gone before the blobs are)
+    Fetcher fx;
+    auto can_elide_tile = [&](size_t i) {
+        for (uint32_t t = 0; t < instants; t++)
+            if (mm[2ull * (i * instants + t)] != mm[2ull * (i * instants + t) + 1]) return false;
+        return true;
+    };
+    // ---- bands of tile rows: one when the view is in HBM already (or below the top level), several behind an upload ----
+    uint64_t rows_per_band = subsidelen;
+    if (up && at_bottom && up->band_rows) rows_per_band = std::max<uint64_t>(1, up->band_rows / chunks_sidelen);
+    const bool threaded = rows_per_band < subsidelen;
+    if (threaded) {
+        const int device = Runtime::get().device;
+        fx.th = std::thread([&fx, &fetch, device] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                Job* j;
+                {
+                    std::unique_lock<std::mutex> lk(fx.mu);
+                    fx.cv.wait(lk, [&] { return !fx.q.empty() || fx.closing; });
+                    if (fx.q.empty()) return;
+                    j = fx.q.front();
+                    fx.q.pop_front();
+                }
+                trace("fetch: starts");
+                const int rc = fetch(*j);
+                trace("fetch: done");
+                if (rc != DCDF_OK) {
+                    std::lock_guard<std::mutex> lk(fx.mu);
+                    if (fx.rc == DCDF_OK) fx.rc = rc;
+                }
+            }
+        });
+    }
+    for (uint64_t tr0 = 0; tr0 < subsidelen; tr0 += rows_per_band) {
+        const uint64_t tr1 = std::min<uint64_t>(tr0 + rows_per_band, subsidelen);
+        const size_t i0 = (size_t)(tr0 * subsidelen), i1 = (size_t)(tr1 * subsidelen);
+        if (up) {
+            trace("main: waits for band", (long)(tr0 / rows_per_band));
+            const int urc = up->wait_rows((uint32_t)std::min<uint64_t>(tr1 * chunks_sidelen, rows));
+            if (urc != DCDF_OK) return urc;
+            trace("main: has band", (long)(tr0 / rows_per_band));
+        }
+        // -- per-instant (min, max) of the band's tiles on the device --
+        std::vector<MinMaxTile> mt;
+        std::vector<size_t> mt_tile;
+        for (size_t i = i0; i < i1; i++)
+            if (inside[i]) {
+                const dcdf_tile_desc& t = tiles[i];
+                mt.push_back(MinMaxTile{t.base, t.stride_t, t.stride_r, t.stride_c, t.rows, t.cols});
+                mt_tile.push_back(i);
+            }
+        if (!mt.empty()) {
+            DevBuf d_mt, d_out, d_st;
+            K2R_HIP(d_mt.alloc(mt.size() * sizeof(MinMaxTile)));
+            K2R_HIP(d_out.alloc(mt.size() * instants * 16ull));
+            K2R_HIP(d_st.alloc(4));
+            K2R_HIP(hipMemcpy(d_mt.p, mt.data(), mt.size() * sizeof(MinMaxTile), hipMemcpyHostToDevice));
+            K2R_HIP(hipMemset(d_st.p, 0, 4));
+            hipLaunchKernelGGL(k_tile_minmax, dim3((uint32_t)(mt.size() * instants)), dim3(256), 0, 0, d_mt.as<MinMaxTile>(), instants, buf.dtype,
+                               (uint32_t)buf.fractional_bits, (uint32_t)buf.round, d_out.as<int64_t>(), d_st.as<int32_t>());
+            K2R_HIP(hipGetLastError());
+            std::vector<int64_t> got(mt.size() * instants * 2ull);
+            K2R_HIP(hipMemcpy(got.data(), d_out.p, got.size() * 8, hipMemcpyDeviceToHost));
+            int32_t st = 0;
+            K2R_HIP(hipMemcpy(&st, d_st.p, 4, hipMemcpyDeviceToHost));
+            if (st != 0) return map_status(st);  // to_fixed panics (fixed.rs:39-70)
+            for (size_t q = 0; q < mt.size(); q++)
+                std::memcpy(&mm[2ull * mt_tile[q] * instants], &got[2ull * q * instants], 16ull * instants);
+        }
+        if (!threaded) tm.lap("tile min/max");
+        // -- fractional bits of every float tile that will be built (fixed.rs:96-159), for the whole band at once --
+        std::vector<size_t> frac_of(i1 - i0, 0);
+        std::vector<int32_t> frac_rnd, frac_bits, frac_st;
+        if (buf.dtype == DCDF_F32 || buf.dtype == DCDF_F64) {
+            std::vector<dcdf_tile_desc> ft;
+            for (size_t i = i0; i < i1; i++)
+                if (inside[i] && !can_elide_tile(i)) {
+                    frac_of[i - i0] = ft.size();
+                    ft.push_back(tiles[i]);
+                }
+            frac_rnd.resize(ft.size());
+            frac_bits.resize(ft.size());
+            frac_st.resize(ft.size());
+            if (!ft.empty()) {
+                const int rc = suggest_fraction_batch(ft.data(), ft.size(), frac_rnd.data(), frac_bits.data(), frac_st.data());
+                if (rc != DCDF_OK) return rc;
+            }
+        }
+        // -- elision, sub-builds (superchunk.rs:144-181) --
+        std::vector<dcdf_tile_desc> chunk_descs;
+        std::unique_ptr<Job> job(new Job());
+        for (size_t i = i0; i < i1; i++) {
+            if (!inside[i] || can_elide_tile(i)) continue;
+            elided[i] = 0;
+            dcdf_tile_desc t = tiles[i];
+            bool build_subchunk = at_bottom;
+            if (!at_bottom) build_subchunk = levels_needed(std::max(t.rows, t.cols), k) <= sublevels[0];  // superchunk.rs:155-165
+            if (t.dtype == DCDF_F32 || t.dtype == DCDF_F64) {  // sub_buffer.compute_fractional_bits() (mmbuffer.rs:596-613)
+                const size_t fi = frac_of[i - i0];  // (all tiles of the band in two launches, before this loop)
+                if (frac_st[fi] != DCDF_OK) return frac_st[fi];
+                int32_t bits = frac_bits[fi];
+                if (t.round) bits = std::min<int32_t>(bits, t.fractional_bits);
+                else if (frac_rnd[fi]) return DCDF_ERR_PRECISION;  // panic!("loss of precision")
+                t.fractional_bits = (uint8_t)bits;
+            }
+            Sub sb{};
+            sb.tile = i;
+            sb.chunk = build_subchunk;
+            if (build_subchunk) {
+                chunk_descs.push_back(t);
+                job->chunk_sub.push_back(subs.size());
+            } else {
+                Level sub;
+                const int rc = build_level(cx, t, sublevels, n_sub, &sub);
+                if (rc != DCDF_OK) return rc;
+                sb.obj = sub.node;
+                sb.size = sub.size_self + 1;  // MMStruct3::size (mmstruct.rs:187-197)
+                sb.snapshots = sub.snapshots;
+                sb.logs = sub.logs;
+            }
+            subs.push_back(std::move(sb));
+        }
+        if (chunk_descs.empty()) continue;
+        // every Chunk::build of the band in ONE launch (superchunk.rs:169) on a device-resident session
+        if (!threaded) tm.lap("fractional bits, tiling");
+        if (threaded) trace("main: min/max, elision done; session create");
+        int rc = dcdf_encoder_create(chunk_descs.data(), chunk_descs.size(), k, 0, &job->e);
+        if (rc != DCDF_OK) return rc;
+        Job* const jp = job.get();
+        fx.jobs.push_back(std::move(job));  // (owns the session from here on)
+        if (!threaded) tm.lap("encoder_create");
+        if (threaded) trace("main: session run");
+        rc = dcdf_encoder_run(jp->e, nullptr);
+        if (rc != DCDF_OK) return rc;
+        if (threaded) trace("main: session done");
+        if (!threaded) tm.lap("encoder_run");
+        for (size_t q = 0; q < chunk_descs.size(); q++) {
+            int32_t st = 0;
+            rc = dcdf_encoder_result(jp->e, q, &st, nullptr, nullptr, nullptr, nullptr);
+            if (rc != DCDF_OK) return rc;
+            if (st != DCDF_OK) return st;
+        }
+        if (threaded) {
+            {
+                std::lock_guard<std::mutex> lk(fx.mu);
+                fx.q.push_back(jp);
+            }
+            fx.cv.notify_all();
+        } else {
+            rc = fetch(*jp);
+            if (rc != DCDF_OK) return rc;
+            tm.lap("download + framing + sha256");
         }
     }
+    {
+        const int frc = fx.close();
+        if (frc != DCDF_OK) return frc;
+    }
+    if (threaded) tm.lap("bands: upload | min/max, sessions | download, sha256");
     // ---- instant-major min / max (superchunk.rs:190-198) ----
     std::vector<int64_t> mins(n_tiles * (size_t)instants), maxs(n_tiles * (size_t)instants);
     for (uint32_t t = 0; t < instants; t++)
@@ -436,7 +675,7 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
     std::vector<std::string> hashed;
     int rc = hash_objects(to_hash, hashed);
     if (rc != DCDF_OK) return rc;
-    std::vector<std::string> cids(chunk_cid);
+    std::vector<std::string> cids(chunk_cid.begin(), chunk_cid.begin() + (long)subs.size());
     for (size_t j = 0; j < hash_sub.size(); j++) cids[hash_sub[j]] = hashed[j];
     std::vector<std::string> external;
     std::map<std::string, uint32_t> ext_index;
@@ -537,45 +776,40 @@ extern "C" int dcdf_superchunk_build(const dcdf_tile_desc* buffer, const uint32_
     if (!Runtime::get().ok) return DCDF_ERR_NO_DEVICE;
     dcdf_tile_desc dev = *buffer;
     DevBuf stage;
-    if (mem == DCDF_MEM_HOST) {  // the whole view goes to HBM once; every tile below is a strided view of that copy
+    StepTimer tm_up;
+    Upload up;  // (joined before `stage` is released)
+    const bool from_host = mem == DCDF_MEM_HOST;
+    if (from_host) {  // the whole view goes to HBM once; every tile below is a strided view of that copy
         const size_t es = esize(buffer->dtype);
         const uint64_t T = buffer->instants, R = buffer->rows, Cc = buffer->cols;
-        const int64_t st = buffer->stride_t, sr = buffer->stride_r, sc = buffer->stride_c;
-        const uint8_t* const base = (const uint8_t*)buffer->base;
-        K2R_HIP(stage.alloc((size_t)(T * R * Cc) * es));
-        if (sc == 1 && sr == (int64_t)Cc && st == (int64_t)(R * Cc)) {
-            // contiguous: one copy straight from the caller's array
-            K2R_HIP(hipMemcpy(stage.p, base, (size_t)(T * R * Cc) * es, hipMemcpyHostToDevice));
-        } else if (sc == 1 && sr >= (int64_t)Cc && st >= 0 && sr >= 0) {
-            // unit column stride (a row-/column-cropped window of a larger array): one 2-D copy per instant, the row pitch does
-            // the gathering -- no dense host copy, no per-element work
-            for (uint64_t t = 0; t < T; t++)
-                K2R_HIP(hipMemcpy2D((uint8_t*)stage.p + (size_t)(t * R * Cc) * es, (size_t)Cc * es, base + (int64_t)t * st * (int64_t)es,
-                                    (size_t)sr * es, (size_t)Cc * es, (size_t)R, hipMemcpyHostToDevice));
-        } else {
-            // general strides (transposed / reversed / stepped views): gathered row by row into one instant's worth of staging
-            std::vector<uint8_t> inst((size_t)(R * Cc) * es);
-            for (uint64_t t = 0; t < T; t++) {
-                uint8_t* d = inst.data();
-                for (uint64_t r = 0; r < R; r++) {
-                    const uint8_t* row = base + ((int64_t)t * st + (int64_t)r * sr) * (int64_t)es;
-                    if (es == 4)
-                        for (uint64_t c = 0; c < Cc; c++, d += 4) *(uint32_t*)d = *(const uint32_t*)(row + (int64_t)c * sc * 4);
-                    else
-                        for (uint64_t c = 0; c < Cc; c++, d += 8) *(uint64_t*)d = *(const uint64_t*)(row + (int64_t)c * sc * 8);
-                }
-                K2R_HIP(hipMemcpy((uint8_t*)stage.p + (size_t)(t * R * Cc) * es, inst.data(), inst.size(), hipMemcpyHostToDevice));
-            }
-        }
+        K2R_HIP(stage.alloc_pooled((size_t)(T * R * Cc) * es));
         dev.base = stage.p;
         dev.stride_c = 1;
         dev.stride_r = buffer->cols;
         dev.stride_t = (int64_t)buffer->rows * buffer->cols;
+        // Bands: whole rows of bottom-level tiles, a few hundred MB each (K2R_SC_BAND_MB; 0 = one band), when the top level's tiles
+        // are chunks.  The first band's tiles are being encoded while the second is on the link, and so on (build_level).
+        uint64_t band_mb = 512;
+        if (const char* bm = std::getenv("K2R_SC_BAND_MB")) band_mb = (uint64_t)std::max(0, std::atoi(bm));
+        uint32_t band_rows = (uint32_t)R;
+        if (n_levels == 2 && band_mb) {
+            uint64_t cs = 1;
+            for (uint32_t i = 0; i < levels[1] && cs < R; i++) cs *= (uint64_t)k;  // rows of one tile of the top level's grid
+            const uint64_t bytes_per_tile_row = T * std::min<uint64_t>(cs, R) * Cc * es;
+            const uint64_t tile_rows = std::max<uint64_t>(1, ((band_mb << 20) + bytes_per_tile_row - 1) / bytes_per_tile_row);
+            if (cs * tile_rows < R) band_rows = (uint32_t)(cs * tile_rows);
+        }
+        up.band_rows = band_rows < R ? band_rows : 0;
+        trace("call: upload starts");
+        const int urc = up.start(*buffer, (uint8_t*)stage.p, band_rows);
+        if (urc != DCDF_OK) return urc;
     }
     Ctx cx;
     cx.k = k;
     Level top;
-    const int rc = build_level(cx, dev, levels, n_levels, &top);
+    const int rc = build_level(cx, dev, levels, n_levels, &top, from_host ? &up : nullptr);
+    up.join();
+    if (from_host) tm_up.lap("whole call below the node's own hash");
     if (rc != DCDF_OK) return rc;
     std::vector<std::string> tcid;
     const int rc2 = hash_objects({&top.node}, tcid);

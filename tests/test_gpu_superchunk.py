@@ -78,3 +78,22 @@ def test_synthetic_and_float_rasters(dc):
 def test_wrong_levels_are_rejected(dc):
     with pytest.raises(dc.DcdfError):
         dc.Superchunk.build(array_n(16), [2, 3])  # superchunk.rs:104-110 panics
+
+
+@pytest.mark.parametrize("band_mb", ["0", "1"])
+def test_banded_assembly_of_a_host_view(dc, band_mb, monkeypatch):
+    """A host view goes to HBM band of tile rows after band (k2r_superchunk.hip `Upload`), each band's chunks encoded and fetched while
+    the next is on the link: K2R_SC_BAND_MB=1 forces one tile row per band on these small rasters, 0 turns the bands off.  Same
+    objects either way -- dense, row-cropped (2-D copies) and transposed (gathered) views, ints and floats with an elided band."""
+    from dcdf_amd import synth
+    monkeypatch.setenv("K2R_SC_BAND_MB", band_mb)
+    a = synth.cells(0xDCDF0003, 0, 9, 0, 1024, 0, 768, np.int32)                         # 4 x 4 grid of 256-tiles, the last column outside
+    check(dc, a, [2, 8])
+    check(dc, a[:, 100:900, 17:600], [2, 8])                                             # row pitch > cols: the 2-D copy per instant
+    check(dc, a[:, :520, :300].transpose(0, 2, 1), [2, 8])                               # general strides: gathered rows
+    b = a[:5, :700, :600].copy()
+    b[:, 256:512, :] = 7                                                                 # a whole band of uniform tiles: elided
+    check(dc, b, [2, 8])
+    f = (synth.cells(0xDCDF0004, 0, 4, 0, 600, 0, 300, np.int32) / 4.0).astype(np.float32)
+    f[1, 300, 5] = np.nan
+    check(dc, f, [2, 8], fractional_bits=2)
