@@ -1296,6 +1296,62 @@ k_parse_chunks(const uint8_t* __restrict__ slab, const uint64_t* __restrict__ of
     m.narrow32 = narrow ? 1u : 0u;
     meta[i] = m;
 }
+// Structural validation of the instants k_parse_chunks described: the checks dcdf_chunk_open makes on the host (every count a
+// decoder relies on against the bitmaps' popcounts, the rank index of every BitMap), by one wave per instant.  bad[chunk] != 0
+// afterwards: the stream is not a chunk of this format; its handle is refused before any walk chases its indices.
+__device__ uint64_t wave_ones(const uint8_t* b, const BmDesc& d, bool& index_ok) {  // popcount of the bitmap (all lanes get it)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t W = (d.len + 31) / 32, nidx = d.len / 128;  // bitmap.rs:70
+    uint32_t base = 0;
+    for (uint32_t g0 = 0; 4 * g0 < W; g0 += 64) {  // a lane per group of four words = per entry of the rank index
+        const uint32_t g = g0 + lane;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t w = 4 * g + i;
+            if (w < W) {
+                uint32_t x = load_be32(b + d.words_off + 4 * w);
+                const uint32_t left = d.len - 32 * w;
+                if (left < 32) x &= ~(0xffffffffu >> left);  // padding bits do not count
+                cnt += popc32(x);
+            }
+        }
+        const uint32_t inc = GpuExecScan::incl(cnt);
+        if (d.k == 4 && g < nidx && load_be32(b + d.idx_off + 4 * g) != base + inc) index_ok = false;  // bitmap.rs:97-104
+        base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    return base;
+}
+__device__ bool wave_dac_ok(const uint8_t* b, const DacDesc& d, uint64_t expect_len, bool& index_ok) {
+    if (expect_len == 0) return d.nlev == 0;
+    if (d.nlev == 0 || d.nlev > 8 || d.bm[0].len != expect_len) return false;
+    for (uint32_t l = 0; l < d.nlev; l++) {
+        if (d.bm[l].k != 4) return false;
+        const uint64_t next = wave_ones(b, d.bm[l], index_ok);
+        if (l + 1 < d.nlev ? d.bm[l + 1].len != next : next != 0) return false;  // dac.rs:83-90: every hop lands in the next plane
+    }
+    return true;
+}
+__global__ void __launch_bounds__(64)
+k_validate_insts(const uint8_t* __restrict__ slab, const uint64_t* __restrict__ offs, const uint32_t* __restrict__ inst_chunk,
+                 const InstDesc* __restrict__ descs, uint32_t* __restrict__ bad) {
+    const uint32_t ci = inst_chunk[blockIdx.x];
+    const uint8_t* const b = slab + offs[ci];
+    const InstDesc& d = descs[blockIdx.x];
+    bool index_ok = true, ok = true;
+    if (d.k < 2 || d.k > 255 || d.rows == 0 || d.cols == 0 || d.T.k != 4 || (d.is_log && d.E.k != 4)) ok = false;
+    if (ok) {
+        const uint64_t internal = wave_ones(b, d.T, index_ok);
+        const uint64_t visited = 1 + (uint64_t)d.k * d.k * internal;  // snapshot.rs:177: k^2 children per internal node
+        if (d.T.len > visited) ok = false;
+        if (ok && (!wave_dac_ok(b, d.mx, visited, index_ok) || !wave_dac_ok(b, d.mn, internal, index_ok))) ok = false;
+        if (ok && d.is_log) {
+            if (d.E.len != d.T.len - internal) ok = false;  // one eqB bit per T = 0 (log.rs:137-144)
+            else (void)wave_ones(b, d.E, index_ok);
+        }
+    }
+    if (__ballot(!ok || !index_ok) != 0 && (threadIdx.x & 63u) == 0) atomicOr(&bad[ci], 1u);
+}
 // counts of the (query, instant) items the wave walk marked: one thread each over the bitmaps of the item's pieces
 __global__ void __launch_bounds__(64)
 k_search_count(const uint32_t* __restrict__ wbits, const SearchItem* __restrict__ items, const WinQuery* __restrict__ qs, uint32_t n,
@@ -1578,8 +1634,8 @@ struct BatchSlab {  // what the chunks of one dcdf_chunk_open_batch share
 // the bytes are where an encoder session left them (dcdf_encoder_result's device pointers) -- they are packed into one slab,
 // parsed ON the device (k_parse_chunks, one thread per chunk: bounds-checked walk of the same layout, no host copy of the
 // bytes), and the side-16 tables of all their instants are built by ONE launch (k_top_table_batch, a wave per instant).
-// Device input is trusted to be the output of this library's encoders: the popcount cross-checks dcdf_chunk_open makes on
-// untrusted streams are not repeated.  status (may be NULL) receives one code per chunk; out[i] is NULL where it is not 0.
+// Device input gets the same structural validation as dcdf_chunk_open's (k_validate_insts: popcounts against the Dac and eqB
+// lengths, rank indexes), a wave per instant.  status (may be NULL) receives one code per chunk; out[i] is NULL where it is not 0.
 extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t* lens, size_t n, int mem, dcdf_chunk** out,
                                      int32_t* status) {
     if (!bytes || !lens || !out || n == 0 || n > 0x7fffffffu || (mem != DCDF_MEM_HOST && mem != DCDF_MEM_DEVICE)) return DCDF_ERR_BAD_ARG;
@@ -1660,6 +1716,25 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
     std::vector<uint8_t> quirk(total_inst);
     K2R_HIP(hipMemcpy(quirk.data(), d_quirk.p, total_inst, hipMemcpyDeviceToHost));
     tm.lap("parse pass 2 + descs D2H");
+    // structural validation of every instant (the host entry point's checks, a wave per instant), before anything walks them
+    std::vector<uint32_t> inst_chunk(total_inst);
+    for (size_t i = 0; i < n; i++)
+        for (uint32_t j = first[i]; j < first[i + 1]; j++) inst_chunk[j] = (uint32_t)i;
+    K2R_HIP(d_ic.alloc((size_t)total_inst * 4));
+    K2R_HIP(hipMemcpy(d_ic.p, inst_chunk.data(), (size_t)total_inst * 4, hipMemcpyHostToDevice));
+    {
+        DevBuf d_bad;
+        K2R_HIP(d_bad.alloc(n * 4));
+        K2R_HIP(hipMemset(d_bad.p, 0, n * 4));
+        hipLaunchKernelGGL(k_validate_insts, dim3(total_inst), dim3(64), 0, 0, slab->bytes.as<uint8_t>(), d_offs.as<uint64_t>(), d_ic.as<uint32_t>(),
+                           slab->descs.as<InstDesc>(), d_bad.as<uint32_t>());
+        K2R_HIP(hipGetLastError());
+        std::vector<uint32_t> bad(n);
+        K2R_HIP(hipMemcpy(bad.data(), d_bad.p, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++)
+            if (bad[i]) meta2[i].ok = 0;
+    }
+    tm.lap("validation");
     // side-16 tables for the k = 2 chunks of sidelen 32..256: one slab, one launch
     const bool want_top = !std::getenv("K2R_NO_TOP_TABLE");
     std::vector<uint64_t> top_off(n, 0);
@@ -1693,11 +1768,6 @@ extern "C" int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t
     K2R_HIP(hipMemcpy(slab->refs.p, refs.data(), n * sizeof(ChunkRef), hipMemcpyHostToDevice));
     std::vector<uint32_t> ovf(n, 0);
     if (squares) {
-        std::vector<uint32_t> inst_chunk(total_inst);
-        for (size_t i = 0; i < n; i++)
-            for (uint32_t j = first[i]; j < first[i + 1]; j++) inst_chunk[j] = (uint32_t)i;
-        K2R_HIP(d_ic.alloc((size_t)total_inst * 4));
-        K2R_HIP(hipMemcpy(d_ic.p, inst_chunk.data(), (size_t)total_inst * 4, hipMemcpyHostToDevice));
         K2R_HIP(d_ovf.alloc(n * 4));
         K2R_HIP(hipMemset(d_ovf.p, 0, n * 4));
         hipLaunchKernelGGL(k_top_table_batch, dim3(total_inst), dim3(64), 0, 0, slab->refs.as<ChunkRef>(), d_ic.as<uint32_t>(), d_first.as<uint32_t>(),

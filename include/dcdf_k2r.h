@@ -214,8 +214,8 @@ int dcdf_query_fill_cell_batch(dcdf_chunk* const* chunks, const uint32_t* cells,
 /* Opens n chunks at once.  mem = DCDF_MEM_HOST: as n calls of dcdf_chunk_open.  mem = DCDF_MEM_DEVICE: bytes[i] are DEVICE
  * pointers, e.g. dcdf_encoder_result's `device_bytes` -- the streams are packed into one slab, parsed on the device (one
  * thread per chunk, bounds-checked) and the side-16 tables of all their instants are built by one launch; nothing is copied
- * to the host but the per-chunk metadata.  Device input is trusted to come from this library's encoders (the popcount
- * cross-checks dcdf_chunk_open makes on untrusted streams are not repeated).  status (may be NULL): one code per chunk;
+ * to the host but the per-chunk metadata.  Device input gets dcdf_chunk_open's structural validation as well, on the device (a wave per
+ * instant: popcounts against the Dac and eqB lengths, rank indexes).  status (may be NULL): one code per chunk;
  * out[i] = NULL where it is not 0.  Every handle is closed with dcdf_chunk_close; the slab goes with the last one. */
 int dcdf_chunk_open_batch(const uint8_t* const* bytes, const uint64_t* lens, size_t n, int mem, dcdf_chunk** out,
                           int32_t* status);

@@ -324,6 +324,61 @@ def test_malformed_chunks_are_rejected_at_open(dc):
     assert rejected >= 10 and opened > 0
 
 
+def test_malformed_chunks_are_rejected_at_device_open(dc):
+    """dcdf_chunk_open_batch(DCDF_MEM_DEVICE) parses AND validates on the device (k_validate_insts: a wave per instant runs the
+    host entry point's checks): the same corrupted streams as above, uploaded, are accepted or refused exactly as
+    dcdf_chunk_open accepts or refuses them, chunk by chunk, and the intact neighbours in the same batch open and answer."""
+    import ctypes as C
+    from dcdf_amd import synth, _lib as L
+    from dcdf_amd.encoder import DeviceBuffer
+    a = synth.cells(77, 0, 5, 0, 32, 0, 32, np.int32)
+    good = bytearray(dc.Chunk.build(a).data.write_to())
+    rng = np.random.default_rng(12)
+    cases = [bytes(good)]
+    t = bytearray(good); t[28 + 4 * (int.from_bytes(good[20:24], "big") // 128)] ^= 0x80; cases.append(bytes(t))  # T[0] flipped
+    t = bytearray(good); t[24:28] = (8).to_bytes(4, "big"); cases.append(bytes(t))    # T bitmap's rank-index stride
+    t = bytearray(good); t[16:20] = (64).to_bytes(4, "big"); cases.append(bytes(t))   # sidelen 64 for a 32 x 32 tile
+    for _ in range(120):  # random byte flips anywhere
+        t = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            t[int(rng.integers(0, len(t)))] ^= int(rng.integers(1, 256))
+        cases.append(bytes(t))
+    cases.append(bytes(good))
+    expect = []
+    for data in cases:  # what the host entry point says
+        try:
+            dc.Chunk(data).close()
+            expect.append(0)
+        except dc.DcdfError as e:
+            expect.append(e.code)
+    n = len(cases)
+    offs = np.cumsum([0] + [(len(c) + 255) & ~255 for c in cases])
+    buf = DeviceBuffer(int(offs[-1]) + 256)
+    for c, o in zip(cases, offs):
+        buf.write(int(o), np.frombuffer(c, dtype=np.uint8))
+    ptrs = (C.c_void_p * n)(*[buf.ptr + int(o) for o in offs[:-1]])
+    lens = (C.c_uint64 * n)(*[len(c) for c in cases])
+    hs = (C.c_void_p * n)()
+    st = (C.c_int32 * n)()
+    L.check(L.lib().dcdf_chunk_open_batch(ptrs, lens, C.c_size_t(n), L.MEM_DEVICE, hs, st), "chunk_open_batch")
+    got = [int(x) for x in st]
+    assert [g != 0 for g in got] == [e != 0 for e in expect], [(i, g, e) for i, (g, e) in enumerate(zip(got, expect)) if (g != 0) != (e != 0)]
+    assert got[0] == 0 and got[-1] == 0 and got[1] != 0 and got[2] != 0 and got[3] != 0 and sum(g != 0 for g in got) >= 10
+    cube = (C.c_uint32 * 6)(0, 5, 0, 32, 0, 32)
+    for i in range(n):
+        if got[i] == 0:  # a flip inside value bytes leaves a well-formed chunk: the walk must run without faulting
+            assert hs[i]
+            out = np.zeros((5, 32, 32), dtype=np.int64)
+            L.check(L.lib().dcdf_chunk_fill_window(C.c_void_p(hs[i]), cube, C.c_void_p(out.ctypes.data), L.DCDF_I64, C.c_int64(32 * 32), C.c_int64(32),
+                                                   C.c_int64(1)), "fill_window")
+            if i in (0, n - 1):
+                np.testing.assert_array_equal(out, a)
+            L.lib().dcdf_chunk_close(C.c_void_p(hs[i]))
+        else:
+            assert not hs[i]
+    buf.free()
+
+
 def test_batched_points_typed_windows_and_device_open(dc):
     """The query entry points that do not defeat the kernels (include/dcdf_k2r.h): chunks opened straight from an encoder
     session's device buffers (dcdf_chunk_open_batch: parsed on the device, all side-16 tables in one launch), many gets /
