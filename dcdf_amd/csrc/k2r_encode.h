@@ -1805,6 +1805,11 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
 #else
         constexpr bool kTopWave = false;
 #endif
+#ifdef K2R_TOPDPP  // (built, bit-exact on the GPU, and 0.3 % slower than the phased form in an A/B on one box, 11.18 against 11.14 ms: off)
+        constexpr bool kTopDpp = !EX::kSim && !kTopWave && H >= 7;
+#else
+        constexpr bool kTopDpp = false;
+#endif
         if (kTopWave && have_s) {
             // The GPU form for logs (sidelen 128 and 256).  The tree top as five barrier-separated LDS phases kept fifteen waves idle
             // for most of five phases; the pre-pass is sparse work over a few thousand records; neither needs the other.  So ONE wave
@@ -1861,6 +1866,86 @@ K2R_HD void encode_chunk(EX& ex, const TileArgs& ta, TileResult* res, uint64_t* 
                     }
                 } else if (!(K2R_DIAG_SKIP & 64)) {
                     prepass((uint32_t)tid - 64u, (uint32_t)NT - 64u);
+                }
+            });
+        } else if constexpr (kTopDpp) {
+            // ================= phase 2 on the GPU, sidelen 128 and 256: heights 4..6 in registers, every wave its own ==========
+            // Thread tid owns height-3 node tid and the threads are in Morton order, so the four children of a height-4 node sit in
+            // one quad of lanes, those of a height-5 node in one row of sixteen, those of a height-6 node in one wave: three levels
+            // by DPP reductions, no LDS traffic but the results, no barrier -- all sixteen waves at once, behind their share of the
+            // pre-pass.  One wave then finishes heights 7 and 8 from the height-6 nodes.  (As five barrier-separated LDS phases the
+            // tree top keeps wave 0 busy for 8.1 K cycles of an instant and the other waves waiting; this form takes the phase from
+            // 8.6 K to 7.0 K cycles per wave in the instrumented build -- and the launch from 11.14 to 11.18 ms: the kernel moves its
+            // 46.8 GB at 86 % of the rate of a device-to-device copy, and cycles saved between two loads do not shorten it.)
+            if (have_s && !(K2R_DIAG_SKIP & 64)) ex.par_nosync([&](int tid, EncRegs&) { prepass((uint32_t)tid, (uint32_t)NT); });
+            ex.par([&](int tid, EncRegs&) {
+                int32_t mn = sh.tmin[tid], mx = sh.tmax[tid], sn = 0, sx = 0, df = 0;
+                uint32_t z = 0;  // "not equal"
+                if (have_s) {
+                    sn = sh.smin[tid];
+                    sx = sh.smax[tid];
+                    df = sh.diff[tid];
+                    z = sh.eq[tid] ^ 1u;
+                }
+                auto put = [&](int a, int32_t d) {
+                    sh.tmin[a] = mn;
+                    sh.tmax[a] = mx;
+                    if (have_s) {
+                        sh.smin[a] = sn;
+                        sh.smax[a] = sx;
+                        sh.diff[a] = d;
+                        sh.eq[a] = z ^ 1u;
+                    }
+                };
+                // height 4: quads
+                mn = EX::quad_min(mn); mx = EX::quad_max(mx); sn = EX::quad_min(sn); sx = EX::quad_max(sx);
+                const int32_t d4 = (int32_t)EX::template quad_bcast<0>((uint32_t)df);
+                z = EX::quad_or(z | (df != d4 ? 1u : 0u));
+                if ((tid & 3) == 0) put(C::top_off(4) + (tid >> 2), d4);
+                // height 5: rows of sixteen lanes
+                mn = EX::row_min_of_quads(mn); mx = EX::row_max_of_quads(mx); sn = EX::row_min_of_quads(sn); sx = EX::row_max_of_quads(sx);
+                const int32_t d5 = (int32_t)EX::lane_pull((uint32_t)tid & 48u, (uint32_t)d4);
+                z = EX::row_or_of_quads(z | (d4 != d5 ? 1u : 0u));
+                if ((tid & 15) == 0) put(C::top_off(5) + (tid >> 4), d5);
+                // height 6: the wave
+                const int32_t d6 = (int32_t)ex.lane_value((uint32_t)d5, 0);
+                const uint32_t z6 = EX::wave_or_of_rows(z | (d5 != d6 ? 1u : 0u));
+                mn = EX::wave_min_of_rows(mn); mx = EX::wave_max_of_rows(mx); sn = EX::wave_min_of_rows(sn); sx = EX::wave_max_of_rows(sx);
+                z = z6;
+                if ((tid & 63) == 0) put(C::top_off(6) + (tid >> 6), d6);
+            });
+            ex.par([&](int tid, EncRegs&) {
+                if (tid >= 64) return;
+                constexpr int N6 = 1 << (2 * (H - 6));  // height-6 nodes: 4 (one quad of lanes) or 16 (one row)
+                const int a6 = C::top_off(6) + (tid < N6 ? tid : 0);
+                int32_t mn = sh.tmin[a6], mx = sh.tmax[a6], sn = 0, sx = 0, df = 0;
+                uint32_t z = 0;
+                if (have_s) {
+                    sn = sh.smin[a6];
+                    sx = sh.smax[a6];
+                    df = sh.diff[a6];
+                    z = sh.eq[a6] ^ 1u;
+                }
+                auto put = [&](int a, int32_t d) {
+                    sh.tmin[a] = mn;
+                    sh.tmax[a] = mx;
+                    if (have_s) {
+                        sh.smin[a] = sn;
+                        sh.smax[a] = sx;
+                        sh.diff[a] = d;
+                        sh.eq[a] = z ^ 1u;
+                    }
+                };
+                // height 7: quads of the height-6 nodes
+                mn = EX::quad_min(mn); mx = EX::quad_max(mx); sn = EX::quad_min(sn); sx = EX::quad_max(sx);
+                const int32_t d7 = (int32_t)EX::template quad_bcast<0>((uint32_t)df);
+                z = EX::quad_or(z | (df != d7 ? 1u : 0u));
+                if ((tid & 3) == 0 && tid < N6) put(C::top_off(7) + (tid >> 2), d7);
+                if (H == 8) {  // height 8: the row of sixteen
+                    mn = EX::row_min_of_quads(mn); mx = EX::row_max_of_quads(mx); sn = EX::row_min_of_quads(sn); sx = EX::row_max_of_quads(sx);
+                    const int32_t d8 = (int32_t)ex.lane_value((uint32_t)d7, 0);
+                    z = EX::row_or_of_quads(z | (d7 != d8 ? 1u : 0u));
+                    if (tid == 0) put(C::top_off(8), d8);
                 }
             });
         } else {
