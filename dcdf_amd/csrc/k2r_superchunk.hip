@@ -247,7 +247,8 @@ struct Upload {
     std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv;
-    uint32_t rows_ready = 0, band_rows = 0;
+    uint32_t rows_ready = 0;
+    std::vector<uint32_t> edges;  // band b = rows [edges[b], edges[b + 1]) of every instant; empty or two entries: one band
     int rc = DCDF_OK;
     struct Piece {
         uint32_t t, r0, r1, band;
@@ -281,7 +282,7 @@ struct Upload {
         cv.notify_all();
     }
     void* registered = nullptr;
-    int start(const dcdf_tile_desc& src, uint8_t* dst, uint32_t rows_per_band) {
+    int start(const dcdf_tile_desc& src, uint8_t* dst) {
         const uint64_t T = src.instants, R = src.rows;
         // Page-lock the caller's array for the duration of the call when the view is dense enough for that to pay: the pieces below
         // then go out as plain asynchronous DMA (a piece of pageable memory is locked and unlocked by the runtime per copy: 32 GB/s
@@ -298,8 +299,9 @@ struct Upload {
                 trace("upload: registered", registered ? 1 : 0);
             }
         }
-        for (uint64_t b0 = 0, band = 0; b0 < R; b0 += rows_per_band, band++) {
-            const uint64_t b1 = std::min<uint64_t>(b0 + rows_per_band, R);
+        if (edges.size() < 2) edges = {0u, (uint32_t)R};
+        for (size_t band = 0; band + 1 < edges.size(); band++) {
+            const uint64_t b0 = edges[band], b1 = edges[band + 1];
             for (uint64_t t = 0; t < T; t++) pieces.push_back(Piece{(uint32_t)t, (uint32_t)b0, (uint32_t)b1, (uint32_t)band});
             band_end.push_back((uint32_t)b1);
             band_left.push_back((uint32_t)T);
@@ -505,9 +507,13 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
         return true;
     };
     // ---- bands of tile rows: one when the view is in HBM already (or below the top level), several behind an upload ----
-    uint64_t rows_per_band = subsidelen;
-    if (up && at_bottom && up->band_rows) rows_per_band = std::max<uint64_t>(1, up->band_rows / chunks_sidelen);
-    const bool threaded = rows_per_band < subsidelen;
+    std::vector<uint64_t> tr_edges{0, subsidelen};  // in tile rows
+    if (up && at_bottom && up->edges.size() > 2) {
+        tr_edges.clear();
+        for (size_t b = 0; b + 1 < up->edges.size(); b++) tr_edges.push_back(up->edges[b] / chunks_sidelen);
+        tr_edges.push_back(subsidelen);  // (the tile rows below the view's last row are outside: nothing to wait for)
+    }
+    const bool threaded = tr_edges.size() > 2;
     if (threaded) {
         const int device = Runtime::get().device;
         fx.th = std::thread([&fx, &fetch, device] {
@@ -531,14 +537,14 @@ int build_level(Ctx& cx, const dcdf_tile_desc& buf, const uint32_t* levels, size
             }
         });
     }
-    for (uint64_t tr0 = 0; tr0 < subsidelen; tr0 += rows_per_band) {
-        const uint64_t tr1 = std::min<uint64_t>(tr0 + rows_per_band, subsidelen);
+    for (size_t band = 0; band + 1 < tr_edges.size(); band++) {
+        const uint64_t tr0 = tr_edges[band], tr1 = tr_edges[band + 1];
         const size_t i0 = (size_t)(tr0 * subsidelen), i1 = (size_t)(tr1 * subsidelen);
         if (up) {
-            trace("main: waits for band", (long)(tr0 / rows_per_band));
+            trace("main: waits for band", (long)band);
             const int urc = up->wait_rows((uint32_t)std::min<uint64_t>(tr1 * chunks_sidelen, rows));
             if (urc != DCDF_OK) return urc;
-            trace("main: has band", (long)(tr0 / rows_per_band));
+            trace("main: has band", (long)band);
         }
         // -- per-instant (min, max) of the band's tiles on the device --
         std::vector<MinMaxTile> mt;
@@ -792,16 +798,23 @@ extern "C" int dcdf_superchunk_build(const dcdf_tile_desc* buffer, const uint32_
         uint64_t band_mb = 512;
         if (const char* bm = std::getenv("K2R_SC_BAND_MB")) band_mb = (uint64_t)std::max(0, std::atoi(bm));
         uint32_t band_rows = (uint32_t)R;
+        uint64_t cs = 1;  // rows of one tile of the top level's grid
         if (n_levels == 2 && band_mb) {
-            uint64_t cs = 1;
-            for (uint32_t i = 0; i < levels[1] && cs < R; i++) cs *= (uint64_t)k;  // rows of one tile of the top level's grid
+            for (uint32_t i = 0; i < levels[1] && cs < R; i++) cs *= (uint64_t)k;
             const uint64_t bytes_per_tile_row = T * std::min<uint64_t>(cs, R) * Cc * es;
             const uint64_t tile_rows = std::max<uint64_t>(1, ((band_mb << 20) + bytes_per_tile_row - 1) / bytes_per_tile_row);
             if (cs * tile_rows < R) band_rows = (uint32_t)(cs * tile_rows);
         }
-        up.band_rows = band_rows < R ? band_rows : 0;
+        if (band_rows < R) {
+            for (uint64_t r = 0; r < R; r += band_rows) up.edges.push_back((uint32_t)r);
+            up.edges.push_back((uint32_t)R);
+            // the last band is what the call still has to encode and fetch once the upload is over: halve it (whole tile rows)
+            const size_t nb = up.edges.size() - 1;
+            const uint64_t last0 = up.edges[nb - 1], tiles = (R - last0 + cs - 1) / cs;
+            if (tiles >= 2) up.edges.insert(up.edges.end() - 1, (uint32_t)(last0 + (tiles - tiles / 2) * cs));
+        }
         trace("call: upload starts");
-        const int urc = up.start(*buffer, (uint8_t*)stage.p, band_rows);
+        const int urc = up.start(*buffer, (uint8_t*)stage.p);
         if (urc != DCDF_OK) return urc;
     }
     Ctx cx;

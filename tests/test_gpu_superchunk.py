@@ -97,3 +97,20 @@ def test_banded_assembly_of_a_host_view(dc, band_mb, monkeypatch):
     f = (synth.cells(0xDCDF0004, 0, 4, 0, 600, 0, 300, np.int32) / 4.0).astype(np.float32)
     f[1, 300, 5] = np.nan
     check(dc, f, [2, 8], fractional_bits=2)
+
+
+def test_page_locked_upload_in_uneven_bands(dc, monkeypatch):
+    """A host view of 64 MB or more is page-locked for the call (hipHostRegister) and its last band is halved: [8, 2048, 1024] int32 in
+    bands of 16 MB against the oracle, and the same objects with the registration switched off and with one band."""
+    from dcdf_amd import synth
+    a = synth.cells(0xDCDF0003, 0, 8, 0, 2048, 0, 1024, np.int32)
+    monkeypatch.setenv("K2R_SC_BAND_MB", "16")
+    check(dc, a, [3, 8])
+    ref = dc.Superchunk.build(a, [3, 8])
+    monkeypatch.setenv("K2R_NO_HOST_REGISTER", "1")
+    b = dc.Superchunk.build(a, [3, 8])
+    monkeypatch.setenv("K2R_SC_BAND_MB", "0")
+    c = dc.Superchunk.build(a, [3, 8])
+    for other in (b, c):
+        assert other.cid == ref.cid and set(other.objects) == set(ref.objects)
+        assert all(bytes(other.objects[k]) == bytes(ref.objects[k]) for k in ref.objects)
