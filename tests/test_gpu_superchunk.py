@@ -114,3 +114,17 @@ def test_page_locked_upload_in_uneven_bands(dc, monkeypatch):
     for other in (b, c):
         assert other.cid == ref.cid and set(other.objects) == set(ref.objects)
         assert all(bytes(other.objects[k]) == bytes(ref.objects[k]) for k in ref.objects)
+
+
+def test_error_in_a_later_band_unwinds_the_pipeline(dc, monkeypatch):
+    """A tile of the third band holds an infinity (to_fixed panics, fixed.rs:39-41): the call reports it while the upload and fetch
+    threads of the earlier bands are still running, and the next call finds the rings and pools as it expects them."""
+    from dcdf_amd import synth
+    monkeypatch.setenv("K2R_SC_BAND_MB", "1")
+    f = (synth.cells(0xDCDF0004, 0, 4, 0, 1024, 0, 512, np.int32) / 4.0).astype(np.float32)
+    g = f.copy()
+    g[2, 700, 100] = np.inf
+    with pytest.raises(dc.DcdfError) as e:
+        dc.Superchunk.build(g, [2, 8], fractional_bits=2)
+    assert e.value.code == -2  # DCDF_ERR_NONFINITE
+    check(dc, f, [2, 8], fractional_bits=2)
