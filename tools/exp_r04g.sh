@@ -1,17 +1,9 @@
 #!/bin/bash
-# quick check: encode parity tests, then timing of the shipped library and of VARIANTS
-set -e
+# round 4: rehearsal of the multi-rank bench path on one GPU (gloo backend, both ranks on GPU 0) after the host-side changes of the round
 O=gpurun_out/r04g; mkdir -p $O
-python -m pytest tests/test_gpu_encode.py -m gpu -x -q > $O/pytest.log 2>&1 || { tail -30 $O/pytest.log; exit 1; }
-tail -1 $O/pytest.log
-B="python bench.py --no-gather --cpu-sample 0 --host-sample 0 --verify 8 --steps 5 --warmup 2"
-for v in ship ${VARIANTS:-}; do
-  if [ "$v" = ship ]; then unset DCDF_K2R_LIB; else export DCDF_K2R_LIB=$PWD/dcdf_amd/libdcdf_k2r_$v.so; fi
-  for i in 1 2; do $B > $O/time_${v}_$i.json 2> $O/time_${v}_$i.err; done
-done
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob('gpurun_out/r04g/time_*.json')):
-    d=json.loads(open(f).read().strip().splitlines()[-1])
-    print(f.split('/')[-1], 'kernel_ms %.3f'%d['roofline']['kernel_ms'], 'frac %.4f'%d['roofline']['frac'], 'failed', d['config']['failed_tiles_rank0'], 'verified', d['config']['bytes_verified_vs_oracle'])
+DCDF_BENCH_BACKEND=gloo timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --decode-queries 0 --also= > $O/bench2.json 2> $O/bench2.err || { tail -20 $O/bench2.err; exit 1; }
+python3 - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04g/bench2.json').read().strip().splitlines()[-1])
+print('n_gpus', d['n_gpus'], 'value %.4e'%d['value'], 'ms', d['ms_per_step'], 'sha ok', d['gather'].get('sha_matches_golden'), d['config']['parallelism'])
 PY
