@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--decode-queries", type=int, default=200000,
                     help="after the timed region (full configs[2] int32 raster, N = 1 only): this many configs[4] queries against the "
                          "chunks the session left on the device -> the line's \"decode\" object (0 = skip)")
-    ap.add_argument("--also", default="i64,f32", help="after the timed region (full configs[2] int32 raster, N = 1 only): short runs "
+    ap.add_argument("--also", default="i64,f32,f64", help="after the timed region (full configs[2] int32 raster, N = 1 only): short runs "
                     "of the same raster in these element types -> the line's \"also\" object ('' = skip)")
     return ap.parse_args(argv)
 
